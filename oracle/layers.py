@@ -1,0 +1,325 @@
+"""Bijector layers and the log_prob / sample loops, CPU oracle (test
+infrastructure, see package doc).  Plain Python objects holding tensors; every
+layer exposes the reference's convention ``forward(z) -> (z', log_det)``
+(sampling direction) and ``inverse(z)`` (density direction).
+
+Restated reference code (paths relative to /root/reference/normflow):
+  flows/neural_spline/coupling.py  Coupling :70-125, PiecewiseCoupling :147-159,
+      PiecewiseRationalQuadraticCDF :211-246, PiecewiseRationalQuadraticCoupling :309-343
+  flows/neural_spline/wrapper.py   CoupledRationalQuadraticSpline :69-75 (direction flip)
+  flows/affine/coupling.py         AffineConstFlow :37-53, AffineCoupling :113-168,
+      MaskedAffineFlow :202-222, AffineCouplingBlock :247-258
+  flows/reshape.py                 Split / Merge channel modes :25-29, :50-55
+  flows/mixing.py                  Permute :32-54
+  distributions/base.py            DiagGaussian :632-652
+  core.py                          NormalizingFlow.log_prob :170-183, .sample :150-155
+"""
+import numpy as np
+import torch
+
+from . import rqs, masks
+
+
+def _row_sum(x):
+    """utils/nn.py:131-134 sum_except_batch."""
+    return torch.sum(x, dim=list(range(1, x.dim())))
+
+
+class RQSCDF:
+    """Per-feature spline with parameters shared over the batch
+    (coupling.py:165-246).  No 1/sqrt(hidden) scaling is applied here."""
+
+    def __init__(self, uw, uh, ud, tails, tail_bound,
+                 min_bin_width=rqs.MIN_BIN_WIDTH, min_bin_height=rqs.MIN_BIN_HEIGHT,
+                 min_derivative=rqs.MIN_DERIVATIVE):
+        self.uw, self.uh, self.ud = uw, uh, ud
+        self.tails, self.tail_bound = tails, tail_bound
+        self.mins = (min_bin_width, min_bin_height, min_derivative)
+
+    def _run(self, x, inverse):
+        n = x.shape[0]
+        uw = self.uw[None, ...].expand(n, *self.uw.shape)      # :208-209
+        uh = self.uh[None, ...].expand(n, *self.uh.shape)
+        ud = self.ud[None, ...].expand(n, *self.ud.shape)
+        kw = dict(inverse=inverse, min_bin_width=self.mins[0],
+                  min_bin_height=self.mins[1], min_derivative=self.mins[2])
+        if self.tails is None:                                  # :218-226
+            y, lad = rqs.rq_spline(x, uw, uh, ud, **kw)
+        else:
+            y, lad = rqs.rq_spline_tails(x, uw, uh, ud, tails=self.tails,
+                                         tail_bound=self.tail_bound, **kw)
+        return y, _row_sum(lad)                                 # :240
+
+    def forward(self, x):
+        return self._run(x, False)
+
+    def inverse(self, x):
+        return self._run(x, True)
+
+
+class RQSCoupling:
+    """nsf-convention RQS coupling: ``nsf_forward`` is the density direction.
+    ``conditioner(identity_split, context) -> [B, d_t * P]``."""
+
+    def __init__(self, identity_idx, transform_idx, conditioner, num_bins, tails,
+                 tail_bound, hidden_features=None, uncond=None,
+                 min_bin_width=rqs.MIN_BIN_WIDTH, min_bin_height=rqs.MIN_BIN_HEIGHT,
+                 min_derivative=rqs.MIN_DERIVATIVE):
+        self.idf, self.tf = identity_idx, transform_idx
+        self.conditioner = conditioner
+        self.k, self.tails, self.tail_bound = num_bins, tails, tail_bound
+        self.hidden = hidden_features
+        self.uncond = uncond
+        self.mins = (min_bin_width, min_bin_height, min_derivative)
+
+    def _spline(self, x, params, inverse):
+        """coupling.py:147-159 + :309-343 for 2-D inputs."""
+        b, d = x.shape
+        p = params.reshape(b, d, -1)                            # :155
+        uw = p[..., :self.k]
+        uh = p[..., self.k:2 * self.k]
+        ud = p[..., 2 * self.k:]
+        if self.hidden is not None:                             # :314-316 (in place on views)
+            uw /= np.sqrt(self.hidden)
+            uh /= np.sqrt(self.hidden)
+        kw = dict(inverse=inverse, min_bin_width=self.mins[0],
+                  min_bin_height=self.mins[1], min_derivative=self.mins[2])
+        if self.tails is None:
+            y, lad = rqs.rq_spline(x, uw, uh, ud, **kw)
+        else:
+            y, lad = rqs.rq_spline_tails(x, uw, uh, ud, tails=self.tails,
+                                         tail_bound=self.tail_bound, **kw)
+        return y, _row_sum(lad)                                 # :159
+
+    def nsf_forward(self, x, context=None):
+        """coupling.py:70-96: conditioner on the untouched identity half, spline
+        on the transform half, THEN the unconditional spline on the identity
+        half; both halves scattered into a fresh tensor."""
+        xi, xt = x[:, self.idf], x[:, self.tf]
+        params = self.conditioner(xi, context)
+        yt, lad = self._spline(xt, params, False)
+        if self.uncond is not None:
+            xi, lad_i = self.uncond.forward(xi)
+            lad = lad + lad_i
+        y = torch.empty_like(x)
+        y[:, self.idf] = xi
+        y[:, self.tf] = yt
+        return y, lad
+
+    def nsf_inverse(self, x, context=None):
+        """coupling.py:98-125: the unconditional inverse runs FIRST and the
+        conditioner sees its output."""
+        xi, xt = x[:, self.idf], x[:, self.tf]
+        lad = 0.0
+        if self.uncond is not None:
+            xi, lad = self.uncond.inverse(xi)
+        params = self.conditioner(xi, context)
+        yt, lad_t = self._spline(xt, params, True)
+        lad = lad + lad_t
+        y = torch.empty_like(x)
+        y[:, self.idf] = xi
+        y[:, self.tf] = yt
+        return y, lad
+
+    # normflow convention used by the wrapper (wrapper.py:69-75): forward is the
+    # nsf inverse and vice versa, log_det flattened to [B].
+    def forward(self, z, context=None):
+        y, ld = self.nsf_inverse(z, context)
+        return y, ld.view(-1)
+
+    def inverse(self, z, context=None):
+        y, ld = self.nsf_forward(z, context)
+        return y, ld.view(-1)
+
+
+class AffineCoupling:
+    """flows/affine/coupling.py:113-168 on an already split pair [z1, z2].
+    ``param_fn(z1)`` returns interleaved (shift, scale) along dim 1."""
+
+    def __init__(self, param_fn, scale=True, scale_map="exp"):
+        self.param_fn, self.scale, self.scale_map = param_fn, scale, scale_map
+
+    def _apply(self, z, inverse):
+        z1, z2 = z
+        param = self.param_fn(z1)
+        if not self.scale:                                      # :139-141 / :165-167
+            return [z1, z2 - param if inverse else z2 + param], 0
+        shift = param[:, 0::2, ...]                             # :122-123
+        sc = param[:, 1::2, ...]
+        dims = list(range(1, shift.dim()))
+        if self.scale_map == "exp":                             # :124-126 / :150-152
+            if inverse:
+                return [z1, (z2 - shift) * torch.exp(-sc)], -torch.sum(sc, dim=dims)
+            return [z1, z2 * torch.exp(sc) + shift], torch.sum(sc, dim=dims)
+        if self.scale_map not in ("sigmoid", "sigmoid_inv"):
+            raise NotImplementedError("This scale map is not implemented.")
+        sg = torch.sigmoid(sc + 2)
+        lsum = torch.sum(torch.log(sg), dim=dims)
+        divide = (self.scale_map == "sigmoid") != inverse       # :127-136 / :153-162
+        if inverse:
+            z2n = (z2 - shift) / sg if divide else (z2 - shift) * sg
+        else:
+            z2n = z2 / sg + shift if divide else z2 * sg + shift
+        return [z1, z2n], (-lsum if divide else lsum)
+
+    def forward(self, z):
+        return self._apply(z, False)
+
+    def inverse(self, z):
+        return self._apply(z, True)
+
+
+class AffineCouplingBlock:
+    """Split -> AffineCoupling -> Merge (coupling.py:225-258; reshape.py
+    channel / channel_inv modes :25-29, :50-55)."""
+
+    def __init__(self, param_fn, scale=True, scale_map="exp", split_mode="channel"):
+        if split_mode not in ("channel", "channel_inv"):
+            raise NotImplementedError("Mode " + split_mode + " is not implemented.")
+        self.core = AffineCoupling(param_fn, scale, scale_map)
+        self.flip = split_mode == "channel_inv"
+
+    def _run(self, z, inverse):
+        tot = torch.zeros(z.shape[0], dtype=z.dtype)
+        a, b = z.chunk(2, dim=1)
+        pair = [b, a] if self.flip else [a, b]
+        pair, ld = (self.core.inverse if inverse else self.core.forward)(pair)
+        tot += ld
+        out = torch.cat([pair[1], pair[0]] if self.flip else pair, 1)
+        return out, tot
+
+    def forward(self, z):
+        return self._run(z, False)
+
+    def inverse(self, z):
+        return self._run(z, True)
+
+
+class MaskedAffine:
+    """coupling.py:171-222; ``b`` is the [1, D] float mask buffer, ``s_fn`` /
+    ``t_fn`` map the masked input to full-width scale / shift (None -> zeros)."""
+
+    def __init__(self, b, s_fn=None, t_fn=None):
+        self.b = b
+        self.s_fn = s_fn if s_fn is not None else torch.zeros_like
+        self.t_fn = t_fn if t_fn is not None else torch.zeros_like
+
+    def _st(self, z):
+        zm = self.b * z
+        nan = torch.tensor(np.nan, dtype=z.dtype)
+        s = self.s_fn(zm)
+        s = torch.where(torch.isfinite(s), s, nan)              # :205-206
+        t = self.t_fn(zm)
+        t = torch.where(torch.isfinite(t), t, nan)              # :207-208
+        return zm, s, t
+
+    def forward(self, z):
+        zm, s, t = self._st(z)
+        out = zm + (1 - self.b) * (z * torch.exp(s) + t)        # :209
+        return out, torch.sum((1 - self.b) * s, dim=list(range(1, self.b.dim())))
+
+    def inverse(self, z):
+        zm, s, t = self._st(z)
+        out = zm + (1 - self.b) * (z - t) * torch.exp(-s)       # :220
+        return out, -torch.sum((1 - self.b) * s, dim=list(range(1, self.b.dim())))
+
+
+class AffineConst:
+    """AffineConstFlow, coupling.py:10-53: per-feature scale/shift, log_det a
+    0-dim tensor times the product of broadcast (size-1) non-batch dims."""
+
+    def __init__(self, s, t):
+        self.s, self.t = s, t
+        self.bdims = [i for i, n in enumerate(s.shape) if n == 1]
+
+    def _mult(self, z):
+        return int(np.prod([z.size(i) for i in self.bdims[1:]])) if len(self.bdims) > 1 else 1
+
+    def forward(self, z):
+        return z * torch.exp(self.s) + self.t, self._mult(z) * torch.sum(self.s)
+
+    def inverse(self, z):
+        return (z - self.t) * torch.exp(-self.s), -self._mult(z) * torch.sum(self.s)
+
+
+class Permute:
+    """mixing.py:10-54."""
+
+    def __init__(self, num_channels, mode="shuffle", perm=None, inv_perm=None):
+        self.c, self.mode, self.perm, self.inv_perm = num_channels, mode, perm, inv_perm
+        if mode not in ("shuffle", "swap"):
+            raise NotImplementedError("The mode " + mode + " is not implemented.")
+
+    def forward(self, z):
+        idx = self.perm if self.mode == "shuffle" else masks.swap_index(self.c, False)
+        return z[:, idx, ...], 0
+
+    def inverse(self, z):
+        idx = self.inv_perm if self.mode == "shuffle" else masks.swap_index(self.c, True)
+        return z[:, idx, ...], 0
+
+
+class DiagGaussian:
+    """distributions/base.py:609-652; ``loc`` / ``log_scale`` are [1, *shape]."""
+
+    def __init__(self, loc, log_scale, temperature=None):
+        self.loc, self.log_scale, self.temperature = loc, log_scale, temperature
+        self.d = int(np.prod(loc.shape[1:]))
+        self.dims = list(range(1, loc.dim()))
+
+    def _ls(self):
+        if self.temperature is None:
+            return self.log_scale
+        return self.log_scale + np.log(self.temperature)
+
+    def from_noise(self, eps):
+        """base.py:632-642 with the standard-normal draw ``eps`` supplied by the
+        caller (RNG streams differ between devices; the draw is an input)."""
+        ls = self._ls()
+        z = self.loc + torch.exp(ls) * eps
+        logp = -0.5 * self.d * np.log(2 * np.pi) - torch.sum(ls + 0.5 * torch.pow(eps, 2), self.dims)
+        return z, logp
+
+    def log_prob(self, z):
+        """base.py:644-652."""
+        ls = self._ls()
+        return -0.5 * self.d * np.log(2 * np.pi) - torch.sum(
+            ls + 0.5 * torch.pow((z - self.loc) / torch.exp(ls), 2), self.dims)
+
+
+def _call(fn, z, context):
+    return fn(z, context) if context is not None else fn(z)
+
+
+class Stack:
+    """core.py NormalizingFlow loops.  ``context`` (optional) is handed to every
+    layer that takes one (the conditional RQS couplings of config C3)."""
+
+    def __init__(self, q0, flows):
+        self.q0, self.flows = q0, list(flows)
+
+    def log_prob(self, x, context=None, trace=None):
+        """core.py:176-183: walk the flows backwards through ``inverse``, add
+        each log_det, finish with the base log-density."""
+        log_q = torch.zeros(len(x), dtype=x.dtype)
+        z = x
+        for f in reversed(self.flows):
+            takes_ctx = isinstance(f, RQSCoupling)
+            z, ld = _call(f.inverse, z, context if takes_ctx else None)
+            log_q += ld
+            if trace is not None:
+                trace.append((z, ld))
+        log_q += self.q0.log_prob(z)
+        return log_q
+
+    def sample_from(self, eps, context=None, trace=None):
+        """core.py:150-155 with the base noise supplied: z0, log_q from q0, then
+        every flow forward, subtracting its log_det."""
+        z, log_q = self.q0.from_noise(eps)
+        for f in self.flows:
+            takes_ctx = isinstance(f, RQSCoupling)
+            z, ld = _call(f.forward, z, context if takes_ctx else None)
+            log_q -= ld
+            if trace is not None:
+                trace.append((z, ld))
+        return z, log_q

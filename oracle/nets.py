@@ -1,0 +1,46 @@
+"""Conditioner networks as pure functions of a state dict, CPU oracle (test
+infrastructure).  The conditioners are the *callees* of the hot path: dense
+layers whose outputs parameterise the bijector.
+
+* ``residual_net`` <- ``normflow/nets/resnet.py`` ResidualNet :60-106,
+  ResidualBlock :8-57 (no batch norm, dropout p=0 -> identity)
+* ``mlp``          <- ``normflow/nets/mlp.py`` MLP :7-58 (Linear + LeakyReLU)
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _lin(sd, key, x):
+    return F.linear(x, sd[key + ".weight"], sd[key + ".bias"])
+
+
+def residual_net(sd, prefix, x, context=None, activation=F.relu):
+    """resnet.py:92-106.  With a context the first layer sees cat(x, context)
+    (:97-102) and every block gates its branch with
+    glu(cat(branch, context_layer(context))) (:49-56)."""
+    h = _lin(sd, prefix + "initial_layer", x if context is None else torch.cat((x, context), dim=1))
+    i = 0
+    while (prefix + "blocks.%d.linear_layers.0.weight" % i) in sd:
+        bp = prefix + "blocks.%d." % i
+        t = activation(h)                                   # :42
+        t = _lin(sd, bp + "linear_layers.0", t)             # :43
+        t = activation(t)                                   # :46
+        t = _lin(sd, bp + "linear_layers.1", t)             # :48
+        if context is not None:                             # :49-56
+            t = F.glu(torch.cat((t, _lin(sd, bp + "context_layer", context)), dim=1), dim=1)
+        h = h + t                                           # :57
+        i += 1
+    return _lin(sd, prefix + "final_layer", h)              # :105
+
+
+def mlp(sd, prefix, x, leaky=0.0):
+    """mlp.py:30-35,55-58 without output_fn: Linear, LeakyReLU, ..., Linear.
+    Linear layers sit at even positions of ``net`` (keys ``net.{2k}``)."""
+    idx = sorted({int(k[len(prefix) + 4:].split(".")[0]) for k in sd
+                  if k.startswith(prefix + "net.") and k.endswith(".weight")})
+    h = x
+    for n, i in enumerate(idx):
+        h = _lin(sd, prefix + "net.%d" % i, h)
+        if n + 1 < len(idx):
+            h = F.leaky_relu(h, leaky)
+    return h

@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product's HIP library on cuda:0; GPU tests fail (not skip) without it."""
+    import torch
+    assert torch.cuda.is_available(), "GPU test selected but no GPU visible"
+    import vcnf_amd
+    vcnf_amd.lib()          # raises loudly when libvcnf_hip.so is missing
+    return torch.device("cuda:0")

@@ -1,0 +1,430 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures by running the REFERENCE (read-only at
+/root/reference) on seeded inputs.  Runs only in the build container; the GPU
+box never sees the reference, only the .npz files written here.
+
+The reference is pure Python.  `import normflow` needs three packages that are
+absent here and unused by the hot path (eagerpy, pyro, torch._six; SURVEY.md
+section 8c): empty placeholder modules are registered for them before the
+import.  Nothing of the reference is copied: the fixtures hold inputs, integer
+index buffers, state-dict entry names/shapes and the reference's outputs in
+fp32 and fp64.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import synth  # noqa: E402
+
+REF = "/root/reference"
+
+
+def import_reference():
+    def placeholder(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+    placeholder("eagerpy", squeeze=None)
+    pyro = placeholder("pyro")
+    pyro.distributions = placeholder("pyro.distributions", Chi2=object,
+                                     TorchDistribution=object, MultivariateStudentT=object)
+    placeholder("torch._six", inf=float("inf"), nan=float("nan"))
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    import normflow  # noqa
+    return normflow
+
+
+nf = import_reference()
+from normflow.utils import splines as ref_splines          # noqa: E402
+from normflow.utils import masks as ref_masks              # noqa: E402
+from normflow.flows.neural_spline.coupling import PiecewiseRationalQuadraticCoupling  # noqa: E402
+from normflow.nets.resnet import ResidualNet               # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %8.1f KB  %d arrays" % (name, os.path.getsize(path) / 1024, len(arrays)))
+
+
+def rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def both(fn, *tensors):
+    """Run fn on fp32 inputs and on their fp64 casts -> (out32, out64) tuples."""
+    o32 = fn(*[t.clone() for t in tensors])
+    o64 = fn(*[t.double() if t.is_floating_point() else t.clone() for t in tensors])
+    return o32, o64
+
+
+# ---------------------------------------------------------------- G1
+def g1_rqs():
+    out = {}
+    for k in (8, 10, 16):
+        r = rng(100 + k)
+        x = torch.from_numpy(r.random((256, 10), dtype=np.float32))
+        uw = torch.from_numpy(r.standard_normal((256, 10, k)).astype(np.float32))
+        uh = torch.from_numpy(r.standard_normal((256, 10, k)).astype(np.float32))
+        ud = torch.from_numpy(r.standard_normal((256, 10, k + 1)).astype(np.float32))
+        for inv in (False, True):
+            f = lambda a, b, c, d: ref_splines.rational_quadratic_spline(a, b, c, d, inverse=inv)
+            (y32, l32), (y64, l64) = both(f, x, uw, uh, ud)
+            tag = "K%d_%s" % (k, "inv" if inv else "fwd")
+            out[tag + "/y32"], out[tag + "/ld32"] = npy(y32), npy(l32)
+            out[tag + "/y64"], out[tag + "/ld64"] = npy(y64), npy(l64)
+        out["K%d/x" % k], out["K%d/uw" % k] = npy(x), npy(uw)
+        out["K%d/uh" % k], out["K%d/ud" % k] = npy(uh), npy(ud)
+    save("g1_rqs", **out)
+
+
+# ---------------------------------------------------------------- G2
+def g2_tails():
+    out = {}
+    for k, tb in ((8, 3.0), (8, 1.0), (16, 5.0), (5, 2.5)):
+        r = rng(200 + k + int(10 * tb))
+        x = (3.0 * r.standard_normal((256, 10))).astype(np.float32)
+        # exact boundaries, just inside / outside, far outside, zeros
+        edge = np.array([tb, -tb, np.nextafter(np.float32(tb), np.float32(0)),
+                         np.nextafter(np.float32(tb), np.float32(100)), -np.float32(tb) * 1.0000001,
+                         0.0, 100.0, -1e6, 1e-30, -0.0], dtype=np.float32)
+        x[0, :] = edge
+        x = torch.from_numpy(x)
+        uw = torch.from_numpy(r.standard_normal((256, 10, k)).astype(np.float32))
+        uh = torch.from_numpy(r.standard_normal((256, 10, k)).astype(np.float32))
+        ud = torch.from_numpy(r.standard_normal((256, 10, k - 1)).astype(np.float32))
+        tag0 = "K%d_T%g" % (k, tb)
+        for inv in (False, True):
+            f = lambda a, b, c, d: ref_splines.unconstrained_rational_quadratic_spline(
+                a, b, c, d, inverse=inv, tails="linear", tail_bound=tb)
+            (y32, l32), (y64, l64) = both(f, x, uw, uh, ud)
+            tag = tag0 + ("_inv" if inv else "_fwd")
+            out[tag + "/y32"], out[tag + "/ld32"] = npy(y32), npy(l32)
+            out[tag + "/y64"], out[tag + "/ld64"] = npy(y64), npy(l64)
+        out[tag0 + "/x"], out[tag0 + "/uw"] = npy(x), npy(uw)
+        out[tag0 + "/uh"], out[tag0 + "/ud"] = npy(uh), npy(ud)
+    save("g2_rqs_tails", **out)
+
+
+# ---------------------------------------------------------------- helpers for module cases
+def run_module_case(build, seed, inputs, call, skip=()):
+    """build() -> reference module; weights are synthesised; ``call(module,
+    *inputs)`` -> tuple of tensors.  Returns (entries, int_buffers, out32, out64)."""
+    m = build()
+    ents = synth.load_synth(m, seed, skip=skip)
+    ints = synth.int_buffers(m)
+    o32 = call(m, *[t.clone() for t in inputs])
+    m64 = build().double()
+    m64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in m.state_dict().items()})
+    o64 = call(m64, *[t.double() if t.is_floating_point() else t.clone() for t in inputs])
+    return ents, ints, o32, o64, m
+
+
+def pack(out, tag, ents, ints, names, o32, o64):
+    out[tag + "/entries"] = synth.encode_entries(ents)
+    for k, v in ints.items():
+        out[tag + "/int/" + k] = npy(v)
+    for n, a, b in zip(names, o32, o64):
+        out[tag + "/%s32" % n] = npy(a)
+        out[tag + "/%s64" % n] = npy(b)
+
+
+# ---------------------------------------------------------------- G3
+def g3_crqs_layer():
+    out = {}
+    r = rng(300)
+    x = torch.from_numpy((1.5 * r.standard_normal((256, 64))).astype(np.float32))
+    x[0, :8] = torch.tensor([3.0, -3.0, 3.5, -7.0, 0.0, 2.9999998, -2.9999998, 1e-20])
+    out["x"] = npy(x)
+    for rm in (False, True):
+        build = lambda: nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8, reverse_mask=rm)
+        call = lambda m, a: m.inverse(a) + m.forward(a)
+        ents, ints, o32, o64, _ = run_module_case(build, 301 + rm, [x], call)
+        pack(out, "rm%d" % rm, ents, ints, ["inv_z", "inv_ld", "fwd_z", "fwd_ld"], o32, o64)
+    save("g3_crqs_layer", **out)
+
+
+def cond_prqc(features, ctx, hidden, blocks, k, tb, even, mask_kind="alt"):
+    def net(i, o):
+        return ResidualNet(in_features=i, out_features=o, hidden_features=hidden,
+                           context_features=ctx, num_blocks=blocks,
+                           activation=torch.nn.functional.relu, dropout_probability=0.0,
+                           use_batch_norm=False)
+    if mask_kind == "alt":
+        mask = ref_masks.create_alternating_binary_mask(features, even=even)
+    else:
+        mask = ref_masks.create_mid_split_binary_mask(features)
+    return PiecewiseRationalQuadraticCoupling(mask=mask, transform_net_create_fn=net, num_bins=k,
+                                              tails="linear", tail_bound=tb,
+                                              apply_unconditional_transform=True)
+
+
+# ---------------------------------------------------------------- G4
+def g4_cond_prqc():
+    out = {}
+    for tag, (d, c, h, nb, k, tb, kind) in {
+        "d64": (64, 16, 128, 2, 8, 3.0, "alt"),
+        "d21": (21, 5, 48, 1, 10, 2.0, "mid"),
+        "d7k4": (7, 3, 32, 1, 4, 4.0, "alt"),
+    }.items():
+        r = rng(400 + d)
+        x = torch.from_numpy((1.3 * r.standard_normal((256, d))).astype(np.float32))
+        ctx = torch.from_numpy(r.standard_normal((256, c)).astype(np.float32))
+        build = lambda: cond_prqc(d, c, h, nb, k, tb, even=False, mask_kind=kind)
+        call = lambda m, a, b: m.forward(a, b) + m.inverse(a, b)
+        ents, ints, o32, o64, _ = run_module_case(build, 401 + d, [x, ctx], call)
+        pack(out, tag, ents, ints, ["nsf_fwd_z", "nsf_fwd_ld", "nsf_inv_z", "nsf_inv_ld"], o32, o64)
+        out[tag + "/x"], out[tag + "/ctx"] = npy(x), npy(ctx)
+        out[tag + "/cfg"] = np.array([d, c, h, nb, k, tb, 0 if kind == "alt" else 1], dtype=np.float64)
+    save("g4_cond_prqc", **out)
+
+
+# ---------------------------------------------------------------- G5
+class C3Stack(torch.nn.Module):
+    """Config C3 assembled from reference parts only: 12 conditional RQS
+    couplings (nsf convention) + DiagGaussian, looped as core.py:176-183 /
+    :150-155 do."""
+
+    def __init__(self, d=64, c=16, layers=12, hidden=128, blocks=2, k=8, tb=3.0):
+        super().__init__()
+        self.q0 = nf.distributions.DiagGaussian(d)
+        self.flows = torch.nn.ModuleList()
+        for i in range(layers):
+            holder = torch.nn.Module()
+            holder.prqct = cond_prqc(d, c, hidden, blocks, k, tb, even=bool(i % 2))
+            self.flows.append(holder)
+
+    def log_prob(self, x, ctx):
+        log_q = torch.zeros(len(x), dtype=x.dtype)
+        z, lds = x, []
+        for i in range(len(self.flows) - 1, -1, -1):
+            z, ld = self.flows[i].prqct.forward(z, ctx)     # wrapper.inverse -> prqct(z)
+            ld = ld.view(-1)
+            log_q += ld
+            lds.append(ld)
+        log_q += self.q0.log_prob(z)
+        return z, log_q, torch.stack(lds)
+
+    def sample(self, eps, ctx):
+        z = self.q0.loc + torch.exp(self.q0.log_scale) * eps     # base.py:639
+        log_q = -0.5 * self.q0.d * np.log(2 * np.pi) - torch.sum(
+            self.q0.log_scale + 0.5 * torch.pow(eps, 2), 1)      # base.py:640-641
+        lds = []
+        for f in self.flows:
+            z, ld = f.prqct.inverse(z, ctx)                      # wrapper.forward -> prqct.inverse
+            ld = ld.view(-1)
+            log_q -= ld
+            lds.append(ld)
+        return z, log_q, torch.stack(lds)
+
+
+def g5_c3_stack():
+    out = {}
+    r = rng(500)
+    b = 256
+    x = torch.from_numpy(r.standard_normal((b, 64)).astype(np.float32))
+    ctx = torch.from_numpy(r.standard_normal((b, 16)).astype(np.float32))
+    eps = torch.from_numpy(r.standard_normal((b, 64)).astype(np.float32))
+    call = lambda m, a, c, e: m.log_prob(a, c) + m.sample(e, c)
+    ents, ints, o32, o64, _ = run_module_case(C3Stack, 501, [x, ctx, eps], call)
+    pack(out, "c3", ents, ints, ["lp_z", "lp", "lp_lds", "s_z", "s_logq", "s_lds"], o32, o64)
+    out["x"], out["ctx"], out["eps"] = npy(x), npy(ctx), npy(eps)
+    save("g5_c3_stack", **out)
+
+
+# ---------------------------------------------------------------- G6
+def g6_affine():
+    out = {}
+    for d in (2, 32, 33):
+        r = rng(600 + d)
+        x = torch.from_numpy(r.standard_normal((128, d)).astype(np.float32))
+        out["d%d/x" % d] = npy(x)
+        d1 = (d + 1) // 2          # chunk(2): first half ceil
+        d2 = d - d1
+        for sm in ("exp", "sigmoid", "sigmoid_inv", "noscale"):
+            for mode in ("channel", "channel_inv"):
+                cin, cout = (d1, d2) if mode == "channel" else (d2, d1)
+                scale = sm != "noscale"
+                width = (2 if scale else 1) * cout
+                build = lambda: nf.flows.AffineCouplingBlock(
+                    nf.nets.MLP([cin, 24, 24, width], init_zeros=False), scale=scale,
+                    scale_map=sm if scale else "exp", split_mode=mode)
+                call = lambda m, a: m.forward(a.clone()) + m.inverse(a.clone())
+                ents, ints, o32, o64, _ = run_module_case(build, 601 + d, [x], call)
+                pack(out, "d%d/%s/%s" % (d, sm, mode), ents, ints,
+                     ["fwd_z", "fwd_ld", "inv_z", "inv_ld"], o32, o64)
+    save("g6_affine", **out)
+
+
+# ---------------------------------------------------------------- G7
+def g7_masked_affine():
+    out = {}
+    for d in (2, 9, 30):
+        r = rng(700 + d)
+        x = torch.from_numpy(r.standard_normal((128, d)).astype(np.float32))
+        bmask = torch.tensor([1.0 if i % 2 == 0 else 0.0 for i in range(d)])
+        for variant in ("st", "t_only", "s_only", "inf"):
+            def build():
+                s = nf.nets.MLP([d, 16, d], init_zeros=False) if variant != "t_only" else None
+                t = nf.nets.MLP([d, 16, d], init_zeros=False) if variant != "s_only" else None
+                return nf.flows.MaskedAffineFlow(bmask.clone(), t, s)
+            def call(m, a):
+                if variant == "inf":
+                    m.s.net[2].bias.data[1] = float("inf")       # non-finite scale column
+                    m.t.net[2].bias.data[d - 1] = float("-inf")
+                return m.forward(a) + m.inverse(a)
+            ents, ints, o32, o64, _ = run_module_case(build, 701 + d, [x], call, skip=("b",))
+            pack(out, "d%d/%s" % (d, variant), ents, ints, ["fwd_z", "fwd_ld", "inv_z", "inv_ld"], o32, o64)
+        out["d%d/x" % d], out["d%d/b" % d] = npy(x), npy(bmask)
+    save("g7_masked_affine", **out)
+
+
+# ---------------------------------------------------------------- G8
+def g8_indices():
+    out = {}
+    for d in (2, 5, 32, 64, 1024):
+        for seed in (0, 7):
+            torch.manual_seed(seed)
+            p = nf.flows.Permute(d, mode="shuffle")
+            out["perm/d%d_s%d/perm" % (d, seed)] = npy(p.perm)
+            out["perm/d%d_s%d/inv_perm" % (d, seed)] = npy(p.inv_perm)
+    r = rng(800)
+    for d in (2, 5, 32, 33):
+        x = torch.from_numpy(r.standard_normal((16, d)).astype(np.float32))
+        p = nf.flows.Permute(d, mode="swap")
+        out["swap/d%d/x" % d] = npy(x)
+        out["swap/d%d/fwd" % d] = npy(p.forward(x)[0])
+        out["swap/d%d/inv" % d] = npy(p.inverse(x)[0])
+    for d in (1, 2, 7, 64, 1024):
+        out["mask/alt_even/d%d" % d] = npy(ref_masks.create_alternating_binary_mask(d, even=True))
+        out["mask/alt_odd/d%d" % d] = npy(ref_masks.create_alternating_binary_mask(d, even=False))
+        out["mask/mid/d%d" % d] = npy(ref_masks.create_mid_split_binary_mask(d))
+        for seed in (0, 3):
+            out["mask/rand/d%d_s%d" % (d, seed)] = npy(ref_masks.create_random_binary_mask(d, seed=seed))
+    torch.manual_seed(11)
+    out["mask/rand_global/d64_ms11"] = npy(ref_masks.create_random_binary_mask(64))
+    # feature index buffers of the wrapper for both mask parities
+    for rm in (False, True):
+        m = nf.flows.CoupledRationalQuadraticSpline(9, 1, 8, 4, reverse_mask=rm)
+        out["crqs_idx/rm%d/identity" % rm] = npy(m.prqct.identity_features)
+        out["crqs_idx/rm%d/transform" % rm] = npy(m.prqct.transform_features)
+    save("g8_indices", **out)
+
+
+# ---------------------------------------------------------------- G9
+def g9_diag_gaussian():
+    out = {}
+    for d, temp in ((2, None), (64, None), (64, 0.7), (33, 1.9)):
+        r = rng(900 + d)
+        z = torch.from_numpy((2 * r.standard_normal((128, d))).astype(np.float32))
+        tag = "d%d_T%s" % (d, "none" if temp is None else ("%g" % temp))
+
+        def build():
+            q = nf.distributions.DiagGaussian(d)
+            q.temperature = temp
+            return q
+
+        def call(q, a):
+            torch.manual_seed(123)
+            zs, lp = q.forward(128)
+            torch.manual_seed(123)
+            eps = torch.randn((128, d), dtype=q.loc.dtype)
+            return (q.log_prob(a), zs, lp, eps)
+        ents, ints, o32, o64, _ = run_module_case(build, 901 + d, [z], call)
+        pack(out, tag, ents, ints, ["logp", "s_z", "s_logp", "eps"], o32, o64)
+        out[tag + "/z"] = npy(z)
+        out[tag + "/temp"] = np.array([np.nan if temp is None else temp])
+    save("g9_diag_gaussian", **out)
+
+
+# ---------------------------------------------------------------- G10
+def g10_c1_two_moons():
+    from sklearn.datasets import make_moons
+    out = {}
+    pts, _ = make_moons(4096, noise=0.1, random_state=0)
+    x = torch.from_numpy(pts.astype(np.float32))
+    r = rng(1000)
+    eps = torch.from_numpy(r.standard_normal((4096, 2)).astype(np.float32))
+
+    def build():
+        flows = []
+        for _ in range(4):
+            flows.append(nf.flows.AffineCouplingBlock(nf.nets.MLP([1, 32, 32, 2], init_zeros=True)))
+            flows.append(nf.flows.Permute(2, mode="swap"))
+        m = nf.NormalizingFlow(nf.distributions.DiagGaussian(2), flows)
+        m.categoricals = None          # attribute missing at this HEAD
+        return m
+
+    def call(m, a, e):
+        lp = m.log_prob(a.clone())
+        # sample(): feed the captured base draw (core.py:150-155)
+        z = m.q0.loc + torch.exp(m.q0.log_scale) * e
+        log_q = -0.5 * m.q0.d * np.log(2 * np.pi) - torch.sum(m.q0.log_scale + 0.5 * torch.pow(e, 2), 1)
+        for f in m.flows:
+            z, ld = f(z)
+            log_q -= ld
+        return (lp, z, log_q)
+    ents, ints, o32, o64, _ = run_module_case(build, 1001, [x, eps], call)
+    pack(out, "c1", ents, ints, ["lp", "s_z", "s_logq"], o32, o64)
+    out["x"], out["eps"] = npy(x), npy(eps)
+    save("g10_c1_two_moons", **out)
+
+
+# ---------------------------------------------------------------- C2 (small batch of the tabular config)
+def g12_c2_tabular():
+    out = {}
+    r = rng(1200)
+    x = torch.from_numpy(r.standard_normal((512, 32)).astype(np.float32))
+    eps = torch.from_numpy(r.standard_normal((512, 32)).astype(np.float32))
+
+    def build():
+        flows = []
+        for _ in range(8):
+            flows.append(nf.flows.AffineCouplingBlock(
+                nf.nets.MLP([16, 64, 64, 32], init_zeros=False), scale_map="exp"))
+            flows.append(nf.flows.Permute(32, mode="swap"))
+        m = nf.NormalizingFlow(nf.distributions.DiagGaussian(32), flows)
+        m.categoricals = None
+        return m
+
+    def call(m, a, e):
+        lp = m.log_prob(a.clone())
+        z = m.q0.loc + torch.exp(m.q0.log_scale) * e
+        log_q = -0.5 * m.q0.d * np.log(2 * np.pi) - torch.sum(m.q0.log_scale + 0.5 * torch.pow(e, 2), 1)
+        for f in m.flows:
+            z, ld = f(z)
+            log_q -= ld
+        return (lp, z, log_q)
+    ents, ints, o32, o64, _ = run_module_case(build, 1201, [x, eps], call)
+    pack(out, "c2", ents, ints, ["lp", "s_z", "s_logq"], o32, o64)
+    out["x"], out["eps"] = npy(x), npy(eps)
+    save("g12_c2_tabular", **out)
+
+
+if __name__ == "__main__":
+    g1_rqs()
+    g2_tails()
+    g3_crqs_layer()
+    g4_cond_prqc()
+    g5_c3_stack()
+    g6_affine()
+    g7_masked_affine()
+    g8_indices()
+    g9_diag_gaussian()
+    g10_c1_two_moons()
+    g12_c2_tabular()

@@ -1,0 +1,95 @@
+"""Shared test plumbing: fixture loading and the bridge that builds oracle
+layers from a state dict laid out with the reference's key names."""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import synth
+from oracle import layers as OL, nets as ON, rqs as OR
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def fixture(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as f:
+        return {k: f[k] for k in f.files}
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t if dtype is None else t.to(dtype)
+
+
+def state_for(fx, tag, seed, dtype=torch.float32):
+    """Rebuild the state dict of fixture case ``tag``: synthetic float entries
+    (same PCG64 stream as the generator) + stored integer buffers."""
+    ents = synth.decode_entries(fx[tag + "/entries"])
+    sd = {k: v.to(dtype) for k, v in synth.synth_state(ents, seed).items()}
+    pre = tag + "/int/"
+    for k, v in fx.items():
+        if k.startswith(pre):
+            sd[k[len(pre):]] = T(v)
+    return sd, ents
+
+
+def oracle_rqs_coupling(sd, prefix, num_bins, tail_bound, hidden, tails="linear"):
+    """Oracle RQSCoupling from reference-style keys under ``prefix`` (the
+    ``prqct.`` level)."""
+    uncond = None
+    if prefix + "unconditional_transform.unnormalized_widths" in sd:
+        u = prefix + "unconditional_transform."
+        uncond = OL.RQSCDF(sd[u + "unnormalized_widths"], sd[u + "unnormalized_heights"],
+                           sd[u + "unnormalized_derivatives"], tails, tail_bound)
+    cond = lambda x, ctx: ON.residual_net(sd, prefix + "transform_net.", x, ctx, F.relu)
+    return OL.RQSCoupling(sd[prefix + "identity_features"], sd[prefix + "transform_features"],
+                          cond, num_bins, tails, tail_bound, hidden_features=hidden, uncond=uncond)
+
+
+def oracle_c3_stack(sd, layers=12, num_bins=8, tail_bound=3.0, hidden=128):
+    flows = [oracle_rqs_coupling(sd, "flows.%d.prqct." % i, num_bins, tail_bound, hidden)
+             for i in range(layers)]
+    return OL.Stack(OL.DiagGaussian(sd["q0.loc"], sd["q0.log_scale"]), flows)
+
+
+def oracle_affine_stack(sd, layers, d, leaky=0.0):
+    """[AffineCouplingBlock(MLP), Permute(d,'swap')] x layers + DiagGaussian."""
+    flows = []
+    for i in range(layers):
+        pm = "flows.%d.flows.1.param_map." % (2 * i)
+        flows.append(OL.AffineCouplingBlock(lambda z, pm=pm: ON.mlp(sd, pm, z, leaky)))
+        flows.append(OL.Permute(d, "swap"))
+    return OL.Stack(OL.DiagGaussian(sd["q0.loc"], sd["q0.log_scale"]), flows)
+
+
+def assert_close(got, want, rtol, atol, what=""):
+    got = got.detach().cpu().double() if torch.is_tensor(got) else torch.as_tensor(got).double()
+    want = want.detach().cpu().double() if torch.is_tensor(want) else torch.as_tensor(np.asarray(want)).double()
+    assert got.shape == want.shape, "%s shape %s vs %s" % (what, tuple(got.shape), tuple(want.shape))
+    nan_g, nan_w = torch.isnan(got), torch.isnan(want)
+    assert torch.equal(nan_g, nan_w), "%s NaN pattern differs" % what
+    g, w = got[~nan_g], want[~nan_w]
+    err = (g - w).abs()
+    tol = atol + rtol * w.abs()
+    bad = err > tol
+    assert not bad.any(), "%s: %d/%d outside tol, max err %.3e (tol there %.3e)" % (
+        what, int(bad.sum()), g.numel(), float(err.max()), float(tol[err.argmax()]))
+
+
+def within_reference_noise(got, ref32, ref64, slack=2.0, floor=1e-6, what=""):
+    """the build must be no worse than the reference's own fp32
+    error: |got - ref64| <= slack*|ref32 - ref64| + floor*(1+|ref64|) elementwise
+    is too strict per element (a different rounding order moves single elements),
+    so the bound is applied to the distribution: max and mean error of the build
+    may not exceed slack x the reference's max / mean fp32 error plus floor."""
+    got = got.detach().cpu().double()
+    r32, r64 = torch.as_tensor(ref32).double(), torch.as_tensor(ref64).double()
+    ok = torch.isfinite(r64) & torch.isfinite(got)
+    scale = 1.0 + r64[ok].abs()
+    e_build = ((got[ok] - r64[ok]).abs() / scale)
+    e_ref = ((r32[ok] - r64[ok]).abs() / scale)
+    assert e_build.max() <= slack * e_ref.max() + floor, "%s max err %.3e vs ref fp32 %.3e" % (
+        what, float(e_build.max()), float(e_ref.max()))
+    assert e_build.mean() <= slack * e_ref.mean() + floor, "%s mean err %.3e vs ref fp32 %.3e" % (
+        what, float(e_build.mean()), float(e_ref.mean()))

@@ -1,0 +1,188 @@
+"""Pin the CPU oracle to the reference: every oracle function is run on the
+fixture inputs and compared with what the reference itself produced
+(tests/golden/*.npz, written by tests/golden/make_golden.py).  fp32 results use
+the same torch CPU ops in the same order, so they agree to a few ulp; fp64 runs
+agree to ~1e-12.  Integer items are bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import (fixture, T, state_for, assert_close, oracle_rqs_coupling,
+                     oracle_c3_stack, oracle_affine_stack)
+from oracle import rqs as OR, masks as OM, nets as ON, layers as OL
+
+F32 = dict(rtol=2e-6, atol=2e-6)
+F64 = dict(rtol=1e-11, atol=1e-11)
+
+
+def _both(fx, key):
+    return ((torch.float32, fx[key + "32"], F32), (torch.float64, fx[key + "64"], F64))
+
+
+@pytest.mark.parametrize("k", [8, 10, 16])
+@pytest.mark.parametrize("inv", [False, True])
+def test_g1_rq_spline(k, inv):
+    fx = fixture("g1_rqs")
+    tag = "K%d_%s" % (k, "inv" if inv else "fwd")
+    for dt, suf, tol in ((torch.float32, "32", F32), (torch.float64, "64", F64)):
+        a = [T(fx["K%d/%s" % (k, n)], dt) for n in ("x", "uw", "uh", "ud")]
+        y, ld = OR.rq_spline(*a, inverse=inv)
+        assert_close(y, fx[tag + "/y" + suf], what=tag + " y", **tol)
+        assert_close(ld, fx[tag + "/ld" + suf], what=tag + " ld", **tol)
+
+
+@pytest.mark.parametrize("case", ["K8_T3", "K8_T1", "K16_T5", "K5_T2.5"])
+@pytest.mark.parametrize("inv", [False, True])
+def test_g2_rq_spline_tails(case, inv):
+    fx = fixture("g2_rqs_tails")
+    tb = float(case.split("_T")[1])
+    tag = case + ("_inv" if inv else "_fwd")
+    for dt, suf, tol in ((torch.float32, "32", F32), (torch.float64, "64", F64)):
+        a = [T(fx["%s/%s" % (case, n)], dt) for n in ("x", "uw", "uh", "ud")]
+        y, ld = OR.rq_spline_tails(*a, inverse=inv, tails="linear", tail_bound=tb)
+        assert_close(y, fx[tag + "/y" + suf], what=tag + " y", **tol)
+        assert_close(ld, fx[tag + "/ld" + suf], what=tag + " ld", **tol)
+
+
+@pytest.mark.parametrize("rm", [0, 1])
+def test_g3_crqs_layer(rm):
+    fx = fixture("g3_crqs_layer")
+    for dt, suf, tol in ((torch.float32, "32", F32), (torch.float64, "64", F64)):
+        sd, _ = state_for(fx, "rm%d" % rm, 301 + rm, dt)
+        lay = oracle_rqs_coupling(sd, "prqct.", 8, 3.0, 128)
+        x = T(fx["x"], dt)
+        z, ld = lay.inverse(x)
+        assert_close(z, fx["rm%d/inv_z%s" % (rm, suf)], what="inv z", **tol)
+        assert_close(ld, fx["rm%d/inv_ld%s" % (rm, suf)], what="inv ld", **tol)
+        z, ld = lay.forward(x)
+        assert_close(z, fx["rm%d/fwd_z%s" % (rm, suf)], what="fwd z", **tol)
+        assert_close(ld, fx["rm%d/fwd_ld%s" % (rm, suf)], what="fwd ld", **tol)
+
+
+@pytest.mark.parametrize("tag", ["d64", "d21", "d7k4"])
+def test_g4_conditional_coupling(tag):
+    fx = fixture("g4_cond_prqc")
+    d, c, h, nb, k, tb, kind = fx[tag + "/cfg"]
+    for dt, suf, tol in ((torch.float32, "32", F32), (torch.float64, "64", F64)):
+        sd, _ = state_for(fx, tag, 401 + int(d), dt)
+        lay = oracle_rqs_coupling(sd, "", int(k), float(tb), int(h))
+        x, ctx = T(fx[tag + "/x"], dt), T(fx[tag + "/ctx"], dt)
+        z, ld = lay.nsf_forward(x, ctx)
+        assert_close(z, fx[tag + "/nsf_fwd_z" + suf], what="fwd z", **tol)
+        assert_close(ld, fx[tag + "/nsf_fwd_ld" + suf], what="fwd ld", **tol)
+        z, ld = lay.nsf_inverse(x, ctx)
+        assert_close(z, fx[tag + "/nsf_inv_z" + suf], what="inv z", **tol)
+        assert_close(ld, fx[tag + "/nsf_inv_ld" + suf], what="inv ld", **tol)
+
+
+def test_g5_c3_stack():
+    fx = fixture("g5_c3_stack")
+    for dt, suf, tol in ((torch.float32, "32", dict(rtol=1e-5, atol=2e-5)), (torch.float64, "64", F64)):
+        sd, _ = state_for(fx, "c3", 501, dt)
+        st = oracle_c3_stack(sd)
+        x, ctx, eps = (T(fx[n], dt) for n in ("x", "ctx", "eps"))
+        tr = []
+        lp = st.log_prob(x, ctx, trace=tr)
+        assert_close(lp, fx["c3/lp" + suf], what="log_prob", **tol)
+        assert_close(tr[-1][0], fx["c3/lp_z" + suf], what="latent", **tol)
+        assert_close(torch.stack([t[1] for t in tr]), fx["c3/lp_lds" + suf], what="layer log_dets", **tol)
+        tr = []
+        z, lq = st.sample_from(eps, ctx, trace=tr)
+        assert_close(z, fx["c3/s_z" + suf], what="sample z", **tol)
+        assert_close(lq, fx["c3/s_logq" + suf], what="sample log_q", **tol)
+        assert_close(torch.stack([t[1] for t in tr]), fx["c3/s_lds" + suf], what="sample log_dets", **tol)
+
+
+@pytest.mark.parametrize("d", [2, 32, 33])
+@pytest.mark.parametrize("sm", ["exp", "sigmoid", "sigmoid_inv", "noscale"])
+@pytest.mark.parametrize("mode", ["channel", "channel_inv"])
+def test_g6_affine_block(d, sm, mode):
+    fx = fixture("g6_affine")
+    tag = "d%d/%s/%s" % (d, sm, mode)
+    for dt, suf, tol in ((torch.float32, "32", F32), (torch.float64, "64", F64)):
+        sd, _ = state_for(fx, tag, 601 + d, dt)
+        blk = OL.AffineCouplingBlock(lambda z: ON.mlp(sd, "flows.1.param_map.", z), scale=sm != "noscale",
+                                     scale_map=sm if sm != "noscale" else "exp", split_mode=mode)
+        x = T(fx["d%d/x" % d], dt)
+        for dirn, fn in (("fwd", blk.forward), ("inv", blk.inverse)):
+            z, ld = fn(x.clone())
+            assert_close(z, fx["%s/%s_z%s" % (tag, dirn, suf)], what=dirn + " z", **tol)
+            assert_close(ld, fx["%s/%s_ld%s" % (tag, dirn, suf)], what=dirn + " ld", **tol)
+
+
+@pytest.mark.parametrize("d", [2, 9, 30])
+@pytest.mark.parametrize("variant", ["st", "t_only", "s_only", "inf"])
+def test_g7_masked_affine(d, variant):
+    fx = fixture("g7_masked_affine")
+    tag = "d%d/%s" % (d, variant)
+    for dt, suf, tol in ((torch.float32, "32", F32), (torch.float64, "64", F64)):
+        sd, _ = state_for(fx, tag, 701 + d, dt)
+        if variant == "inf":
+            sd["s.net.2.bias"][1] = float("inf")
+            sd["t.net.2.bias"][d - 1] = float("-inf")
+        s_fn = (lambda z: ON.mlp(sd, "s.", z)) if variant != "t_only" else None
+        t_fn = (lambda z: ON.mlp(sd, "t.", z)) if variant != "s_only" else None
+        lay = OL.MaskedAffine(T(fx["d%d/b" % d], dt).view(1, -1), s_fn, t_fn)
+        x = T(fx["d%d/x" % d], dt)
+        for dirn, fn in (("fwd", lay.forward), ("inv", lay.inverse)):
+            z, ld = fn(x)
+            assert_close(z, fx["%s/%s_z%s" % (tag, dirn, suf)], what=dirn + " z", **tol)
+            assert_close(ld, fx["%s/%s_ld%s" % (tag, dirn, suf)], what=dirn + " ld", **tol)
+
+
+def test_g8_indices_bit_exact():
+    fx = fixture("g8_indices")
+    for d in (2, 5, 32, 64, 1024):
+        for seed in (0, 7):
+            torch.manual_seed(seed)
+            perm, inv = OM.shuffle_perm(d)
+            assert np.array_equal(perm.numpy(), fx["perm/d%d_s%d/perm" % (d, seed)])
+            assert np.array_equal(inv.numpy(), fx["perm/d%d_s%d/inv_perm" % (d, seed)])
+    for d in (2, 5, 32, 33):
+        x = T(fx["swap/d%d/x" % d])
+        p = OL.Permute(d, "swap")
+        assert np.array_equal(p.forward(x)[0].numpy(), fx["swap/d%d/fwd" % d])
+        assert np.array_equal(p.inverse(x)[0].numpy(), fx["swap/d%d/inv" % d])
+    for d in (1, 2, 7, 64, 1024):
+        for name, got in (("alt_even", OM.alternating_mask(d, True)), ("alt_odd", OM.alternating_mask(d, False)),
+                          ("mid", OM.mid_split_mask(d))):
+            want = fx["mask/%s/d%d" % (name, d)]
+            assert got.dtype == torch.uint8 and np.array_equal(got.numpy(), want)
+        for seed in (0, 3):
+            assert np.array_equal(OM.random_mask(d, seed).numpy(), fx["mask/rand/d%d_s%d" % (d, seed)])
+    torch.manual_seed(11)
+    assert np.array_equal(OM.random_mask(64).numpy(), fx["mask/rand_global/d64_ms11"])
+    for rm in (0, 1):
+        idf, tf = OM.split_features(OM.alternating_mask(9, even=bool(rm)))
+        assert np.array_equal(idf.numpy(), fx["crqs_idx/rm%d/identity" % rm])
+        assert np.array_equal(tf.numpy(), fx["crqs_idx/rm%d/transform" % rm])
+
+
+@pytest.mark.parametrize("tag", ["d2_Tnone", "d64_Tnone", "d64_T0.7", "d33_T1.9"])
+def test_g9_diag_gaussian(tag):
+    fx = fixture("g9_diag_gaussian")
+    d = int(tag[1:].split("_")[0])
+    temp = fx[tag + "/temp"][0]
+    temp = None if np.isnan(temp) else float(temp)
+    for dt, suf, tol in ((torch.float32, "32", F32), (torch.float64, "64", F64)):
+        sd, _ = state_for(fx, tag, 901 + d, dt)
+        q = OL.DiagGaussian(sd["loc"], sd["log_scale"], temp)
+        assert_close(q.log_prob(T(fx[tag + "/z"], dt)), fx[tag + "/logp" + suf], what="log_prob", **tol)
+        z, lp = q.from_noise(T(fx[tag + "/eps" + suf], dt))
+        assert_close(z, fx[tag + "/s_z" + suf], what="sample z", **tol)
+        assert_close(lp, fx[tag + "/s_logp" + suf], what="sample logp", **tol)
+
+
+@pytest.mark.parametrize("name,tag,layers,d,seed", [("g10_c1_two_moons", "c1", 4, 2, 1001),
+                                                    ("g12_c2_tabular", "c2", 8, 32, 1201)])
+def test_affine_stacks(name, tag, layers, d, seed):
+    fx = fixture(name)
+    for dt, suf, tol in ((torch.float32, "32", dict(rtol=1e-5, atol=1e-5)), (torch.float64, "64", F64)):
+        sd, ents = state_for(fx, tag, seed, dt)
+        st = oracle_affine_stack(sd, layers, d)
+        lp = st.log_prob(T(fx["x"], dt))
+        assert_close(lp, fx[tag + "/lp" + suf], what="log_prob", **tol)
+        z, lq = st.sample_from(T(fx["eps"], dt))
+        assert_close(z, fx[tag + "/s_z" + suf], what="sample z", **tol)
+        assert_close(lq, fx[tag + "/s_logq" + suf], what="sample log_q", **tol)
