@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: flow transforms/sec (log_prob + sample) on BASELINE.json's
+config C3 - conditional D=64 (context 16), 12 RQ-spline coupling layers (8 bins,
+linear tails, ResidualNet hidden 128 x 2 blocks), batch 1M per GPU.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one log_prob pass + one sample pass over the rank's batch with all
+inputs already resident in HBM: 2*B transforms (1 transform = one sample through
+the 12-layer stack in one direction, base-distribution end cap included), plus
+the single all-reduce of [sum log_prob, count].  Weak scaling: every rank holds
+its own 1M-sample shard; no sample ever crosses ranks.
+
+The JSON line also carries
+  roofline     - the RQS coupling kernel (dominant HIP kernel): algorithmic bytes
+                 per launch (3464 B per sample-layer) / mean launch
+                 duration measured with HIP events on the launch stream during the
+                 timed region, against the 8 TB/s HBM peak;
+  cpu_baseline - the CPU oracle (op-order-faithful PyTorch-CPU restatement of the
+                 reference path) timed on this box's host cores on a bounded sample
+                 of the same workload (rank 0, N=1 only).  Reported, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import vcnf_amd as nf            # noqa: E402
+from vcnf_amd import _lib        # noqa: E402
+
+D, CTX, LAYERS, HIDDEN, BLOCKS, BINS, TAIL = 64, 16, 12, 128, 2, 8, 3.0
+HBM_PEAK = 8.0e12                                   # MI355X_MICROARCH.md: 8 TB/s spec
+P = 3 * BINS - 1
+BYTES_PER_SAMPLE_LAYER = 4 * D + 4 * (D // 2) * P + 4 * D + 8     # 3464, SURVEY 8(d)
+
+
+def build_model(device, seed=0):
+    """Random-init weights of the C3 architecture exactly as the constructors
+    leave them, except the unconditional spline logits, re-drawn N(0, 0.5^2):
+    the identity init makes all bins equal."""
+    torch.manual_seed(seed)
+    flows = [nf.flows.CoupledRationalQuadraticSpline(D, BLOCKS, HIDDEN, BINS, tail_bound=TAIL,
+                                                     reverse_mask=bool(i % 2), num_context_channels=CTX)
+             for i in range(LAYERS)]
+    model = nf.NormalizingFlow(nf.distributions.DiagGaussian(D), flows)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "unnormalized_" in n:
+                p.normal_(0.0, 0.5)
+    return model.to(device).eval()
+
+
+def cpu_baseline(model, budget_s=20.0):
+    """Oracle (kind 'port') on the host cores, bounded sample of the C3 workload."""
+    from helpers import oracle_c3_stack
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    stack = oracle_c3_stack(sd, layers=LAYERS, num_bins=BINS, tail_bound=TAIL, hidden=HIDDEN)
+    # the GPU box gives one job a 16-core share; more threads than that only oversubscribe
+    cores = max(1, min(16, len(os.sched_getaffinity(0)), torch.get_num_threads()))
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(99)
+
+    def run(b):
+        x, ctx, eps = (torch.randn(b, n, generator=g) for n in (D, CTX, D))
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            stack.log_prob(x, ctx)
+            stack.sample_from(eps, ctx)
+        return time.perf_counter() - t0
+
+    run(512)                                   # warm-up (thread pool, allocator)
+    probe_b = 2048
+    t = run(probe_b)
+    b = int(min(65536, max(probe_b, probe_b * (budget_s / max(t, 1e-3)))))
+    b -= b % 256
+    t = run(b)
+    return {"value": round(2 * b / t, 1), "unit": "transforms/s", "cores": cores, "kind": "port",
+            "sample": "oracle C3 stack, log_prob + sample at batch %d (%.1f s), torch CPU fp32, %d threads"
+                      % (b, t, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1 << 20, help="samples per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+    nf.lib()
+
+    model = build_model(device, seed=0)                      # replicated weights
+    gen = torch.Generator(device=device).manual_seed(1000 + rank)
+    B = args.batch
+    x = torch.randn(B, D, device=device, generator=gen)
+    ctx = torch.randn(B, CTX, device=device, generator=gen)
+    eps = torch.randn(B, D, device=device, generator=gen)
+    evaluator = nf.ShardedEvaluator(model.log_prob)
+
+    def step():
+        lp = model.log_prob(x, ctx)
+        stats = evaluator.reduce_stats(lp)                   # the one collective: [sum log_prob, count]
+        z, lq = model.sample_from(eps, ctx)
+        return stats, z, lq
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        events = []
+        _lib.EVENT_SINK = events
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            stats, z, lq = step()
+        fence()
+        dt = time.perf_counter() - t0
+        _lib.EVENT_SINK = None
+    nf.check_discriminant(device)
+    assert torch.isfinite(stats).all() and torch.isfinite(lq).all()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # dominant kernel: mean duration of the RQS coupling launches inside the timed region
+    durs = [a.elapsed_time(b) * 1e-3 for a, b, _ in events]
+    kern_s = sum(durs) / max(len(durs), 1)
+    achieved = BYTES_PER_SAMPLE_LAYER * B / kern_s if durs else 0.0
+
+    if rank == 0:
+        transforms = 2.0 * B * args.steps * world
+        out = {
+            "metric": "flow transforms/sec (log_prob + sample), D=64 RQ-spline, batch=1M",
+            "value": round(transforms / dt, 1),
+            "unit": "transforms/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: conditional D=64 (cond_dim=16), 12 RQ-spline coupling layers "
+                                   "(8 bins), batch=%d per GPU, log_prob + sample per step" % B,
+                       "batch_per_gpu": B, "layers": LAYERS, "bins": BINS, "hidden": HIDDEN,
+                       "sharding": "batch over %d GPU(s), one all-reduce of [sum log_prob, count]" % world},
+            "roofline": {"bound": "hbm", "kernel": "rqs_coupling_kernel",
+                         "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                         "launches": len(durs), "avg_launch_ms": round(kern_s * 1e3, 4),
+                         "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE_LAYER * B},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

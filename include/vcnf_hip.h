@@ -1,0 +1,157 @@
+/*
+ * vcnf_hip.h - C ABI of the MI355X (gfx950) coupling-flow transform engine.
+ *
+ * The reference (telegraphroad/VCNF, a fork of normflow 1.2) is pure Python: it
+ * has no FFI.  Its hot path sits behind Python classes
+ * (normflow/flows/base.py:6-21, Flow.forward / Flow.inverse).  This header is
+ * the boundary a binding for that path attaches to: every entry point replaces
+ * the arithmetic of the reference function cited above it, on device buffers
+ * the caller owns.  Conventions shared by all entry points:
+ *
+ *   - plain pointers + sizes, fp32 row-major dense buffers in HBM, int32 index
+ *     vectors on the device; no allocation, no host sync, no host callbacks;
+ *   - `stream` is a hipStream_t (NULL = default stream); the call only enqueues;
+ *   - return value: VCNF_OK or a VCNF_ERR_* code (vcnf_status_string());
+ *     arguments are validated on the host BEFORE anything is launched;
+ *   - `logdet` handling: ld_mode VCNF_LD_STORE writes sign*sum, VCNF_LD_ACCUM
+ *     adds sign*sum to what is there (the `log_q += / -= log_det` of
+ *     normflow/core.py:153-155, :179-181 folded into the kernel);
+ *   - direction names follow the reference's nsf code: `inverse == 0` is the
+ *     density direction of a spline (search x knots), `inverse != 0` the
+ *     sampling direction (search y knots, quadratic root).
+ *
+ * See INTEGRATION.md for the ctypes binding that ships in vcnf_amd/_lib.py.
+ */
+#ifndef VCNF_HIP_H
+#define VCNF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VCNF_ABI_VERSION 1
+
+enum {
+  VCNF_OK = 0,
+  VCNF_ERR_NULL = 1,        /* a required pointer is NULL */
+  VCNF_ERR_SHAPE = 2,       /* sizes inconsistent / out of the supported range */
+  VCNF_ERR_ALIGN = 3,       /* a buffer is not 4-byte aligned */
+  VCNF_ERR_VALUE = 4,       /* e.g. min_bin_width * K > 1 (splines.py:104-107) */
+  VCNF_ERR_UNSUPPORTED = 5, /* unknown enum value (tails, scale map) */
+  VCNF_ERR_LAUNCH = 6       /* hipGetLastError() after the launch */
+};
+
+enum { VCNF_LD_STORE = 0, VCNF_LD_ACCUM = 1 };
+enum { VCNF_TAILS_NONE = 0, VCNF_TAILS_LINEAR = 1 };
+enum { VCNF_SCALE_EXP = 0, VCNF_SCALE_SIGMOID = 1, VCNF_SCALE_SIGMOID_INV = 2, VCNF_SCALE_NONE = 3 };
+
+int vcnf_abi_version(void);
+const char* vcnf_status_string(int status);
+
+/* Spline constants.  Replaces the keyword arguments of
+ * unconstrained_rational_quadratic_spline / rational_quadratic_spline
+ * (normflow/utils/splines.py:20-29, :88-96). */
+typedef struct vcnf_rqs_cfg {
+  int32_t num_bins;        /* K */
+  int32_t tails;           /* VCNF_TAILS_* ; LINEAR: K-1 derivative logits, identity outside */
+  float left, right;       /* x interval; LINEAR uses [-tail_bound, tail_bound] */
+  float bottom, top;       /* y interval */
+  float min_bin_width;     /* splines.py:6 */
+  float min_bin_height;    /* splines.py:7 */
+  float min_derivative;    /* splines.py:8 */
+  float wh_scale;          /* multiplies width/height logits: 1/sqrt(hidden_features),
+                              flows/neural_spline/coupling.py:314-316; 1 for none */
+} vcnf_rqs_cfg;
+
+/* Elementwise spline on n independent elements with per-element parameters.
+ * Replaces splines.py:20-85 (tails=LINEAR) and :88-193 (tails=NONE).
+ * uw/uh/ud: element i reads uw[i*ld_w + k], k<K; uh[i*ld_h + k]; ud[i*ld_d + k],
+ * k < K-1 (LINEAR) or K+1 (NONE).  bad_disc (optional, device int32) counts
+ * negative discriminants, the condition the reference asserts on (splines.py:164). */
+int vcnf_rqs_elementwise_f32(const float* x, const float* uw, const float* uh, const float* ud,
+                             int64_t ld_w, int64_t ld_h, int64_t ld_d,
+                             float* y, float* logabsdet, int64_t n,
+                             const vcnf_rqs_cfg* cfg, int inverse, int32_t* bad_disc, void* stream);
+
+/* One RQS coupling layer on x[B,D] -> y[B,D].
+ * Replaces Coupling.forward / .inverse (flows/neural_spline/coupling.py:70-96 /
+ * :98-125) minus the conditioner call, PiecewiseCoupling._coupling_transform
+ * (:147-159), _piecewise_cdf (:309-343), the unconditional per-feature spline
+ * (PiecewiseRationalQuadraticCDF._spline :211-240) and sum_except_batch
+ * (utils/nn.py:131-134).
+ *   params[B, d_t*P] dense, P = 3K-1 (LINEAR) or 3K+1 (NONE): conditioner output.
+ *   transform_idx[d_t], identity_idx[d_id]: feature indices (buffers
+ *     transform_features / identity_features, coupling.py:45-46), d_t+d_id == D.
+ *   shared_w/h[d_id,K], shared_d[d_id, K-1 | K+1]: unconditional spline logits or
+ *     all NULL when apply_unconditional_transform is off; never scaled by wh_scale.
+ *   logdet[B]: per-sample sum over all D features, see ld_mode / sign above. */
+int vcnf_rqs_coupling_f32(const float* x, const float* params,
+                          const int32_t* transform_idx, int32_t d_t,
+                          const int32_t* identity_idx, int32_t d_id,
+                          const float* shared_w, const float* shared_h, const float* shared_d,
+                          float* y, float* logdet, int64_t batch,
+                          const vcnf_rqs_cfg* cfg, int inverse,
+                          int ld_mode, float ld_sign, int32_t* bad_disc, void* stream);
+
+/* Conditioner input for one RQS coupling layer: out[B, d_id + ctx_dim] =
+ * cat(identity_split, context).  With apply_inverse_shared != 0 the identity
+ * columns first go through the INVERSE unconditional spline, which is what the
+ * sampling direction feeds its conditioner (coupling.py:110-114); otherwise the
+ * raw gather of coupling.py:78 (and the concat of nets/resnet.py:100-102). */
+int vcnf_rqs_conditioner_input_f32(const float* x, int64_t batch, int32_t features,
+                                   const int32_t* identity_idx, int32_t d_id,
+                                   const float* context, int32_t ctx_dim,
+                                   const float* shared_w, const float* shared_h, const float* shared_d,
+                                   const vcnf_rqs_cfg* cfg, int apply_inverse_shared,
+                                   float* out, void* stream);
+
+/* Affine coupling on z[B, C, inner] (inner = H*W, 1 for 2-D inputs).
+ * Replaces AffineCoupling.forward / .inverse (flows/affine/coupling.py:113-142 /
+ * :144-168) together with the channel Split / Merge around it
+ * (flows/reshape.py:25-29, :50-55; AffineCouplingBlock :247-258): channels
+ * [t_off, t_off+d_t) are transformed, all other channels are copied.
+ * param[B, n_par*d_t, inner]: channel 2c = shift, 2c+1 = scale logit
+ * (coupling.py:122-123); scale_map NONE: param[B, d_t, inner] is the shift. */
+int vcnf_affine_coupling_f32(const float* z, const float* param, float* out, float* logdet,
+                             int64_t batch, int32_t channels, int32_t inner,
+                             int32_t t_off, int32_t d_t, int scale_map, int inverse,
+                             int ld_mode, float ld_sign, void* stream);
+
+/* MaskedAffineFlow.forward / .inverse (flows/affine/coupling.py:202-211 /
+ * :213-222) on z[B,D]; s,t [B,D] are the scale / shift net outputs (NULL =
+ * zeros, coupling.py:192-200); b[D] the 0/1 float mask.  Non-finite s/t become
+ * NaN (coupling.py:205-208). */
+int vcnf_masked_affine_f32(const float* z, const float* s, const float* t, const float* b,
+                           float* out, float* logdet, int64_t batch, int32_t features,
+                           int inverse, int ld_mode, float ld_sign, void* stream);
+
+/* AffineConstFlow / ActNorm arithmetic (flows/affine/coupling.py:37-53) on
+ * z[B, C, inner] with per-channel s[C], t[C] (either may be NULL = zeros);
+ * the parameter-only log_det (a scalar) is left to the host. */
+int vcnf_affine_const_f32(const float* z, const float* s, const float* t, float* out,
+                          int64_t batch, int32_t channels, int32_t inner, int inverse, void* stream);
+
+/* Column gather out[b, j, :] = z[b, idx[j], :] for z[B, C, inner].
+ * Replaces Permute.forward / .inverse (flows/mixing.py:32-54) and
+ * _Permutation._permute (:219-228). */
+int vcnf_permute_f32(const float* z, const int32_t* idx, float* out,
+                     int64_t batch, int32_t channels, int32_t inner, void* stream);
+
+/* DiagGaussian.log_prob (normflow/distributions/base.py:644-652).
+ * loc, log_scale [D]; log_temperature = log(T) or 0; logp[B] per ld_mode. */
+int vcnf_diag_gaussian_log_prob_f32(const float* z, const float* loc, const float* log_scale,
+                                    float log_temperature, float* logp, int64_t batch,
+                                    int32_t features, int ld_mode, float ld_sign, void* stream);
+
+/* DiagGaussian.forward (base.py:632-642) with the standard-normal draw eps[B,D]
+ * supplied by the caller: z = loc + exp(log_scale) * eps, logp[B]. */
+int vcnf_diag_gaussian_sample_f32(const float* eps, const float* loc, const float* log_scale,
+                                  float log_temperature, float* z, float* logp, int64_t batch,
+                                  int32_t features, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VCNF_HIP_H */

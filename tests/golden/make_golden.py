@@ -122,11 +122,11 @@ def g2_tails():
 
 
 # ---------------------------------------------------------------- helpers for module cases
-def run_module_case(build, seed, inputs, call, skip=()):
+def run_module_case(build, seed, inputs, call, skip=(), final_gain=6.0, weight_gain=1.0):
     """build() -> reference module; weights are synthesised; ``call(module,
     *inputs)`` -> tuple of tensors.  Returns (entries, int_buffers, out32, out64)."""
     m = build()
-    ents = synth.load_synth(m, seed, skip=skip)
+    ents = synth.load_synth(m, seed, skip=skip, final_gain=final_gain, weight_gain=weight_gain)
     ints = synth.int_buffers(m)
     o32 = call(m, *[t.clone() for t in inputs])
     m64 = build().double()
@@ -154,7 +154,7 @@ def g3_crqs_layer():
     for rm in (False, True):
         build = lambda: nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8, reverse_mask=rm)
         call = lambda m, a: m.inverse(a) + m.forward(a)
-        ents, ints, o32, o64, _ = run_module_case(build, 301 + rm, [x], call)
+        ents, ints, o32, o64, _ = run_module_case(build, 301 + rm, [x], call, final_gain=2.0)
         pack(out, "rm%d" % rm, ents, ints, ["inv_z", "inv_ld", "fwd_z", "fwd_ld"], o32, o64)
     save("g3_crqs_layer", **out)
 
@@ -187,7 +187,7 @@ def g4_cond_prqc():
         ctx = torch.from_numpy(r.standard_normal((256, c)).astype(np.float32))
         build = lambda: cond_prqc(d, c, h, nb, k, tb, even=False, mask_kind=kind)
         call = lambda m, a, b: m.forward(a, b) + m.inverse(a, b)
-        ents, ints, o32, o64, _ = run_module_case(build, 401 + d, [x, ctx], call)
+        ents, ints, o32, o64, _ = run_module_case(build, 401 + d, [x, ctx], call, final_gain=2.0)
         pack(out, tag, ents, ints, ["nsf_fwd_z", "nsf_fwd_ld", "nsf_inv_z", "nsf_inv_ld"], o32, o64)
         out[tag + "/x"], out[tag + "/ctx"] = npy(x), npy(ctx)
         out[tag + "/cfg"] = np.array([d, c, h, nb, k, tb, 0 if kind == "alt" else 1], dtype=np.float64)
@@ -241,8 +241,15 @@ def g5_c3_stack():
     ctx = torch.from_numpy(r.standard_normal((b, 16)).astype(np.float32))
     eps = torch.from_numpy(r.standard_normal((b, 64)).astype(np.float32))
     call = lambda m, a, c, e: m.log_prob(a, c) + m.sample(e, c)
-    ents, ints, o32, o64, _ = run_module_case(C3Stack, 501, [x, ctx, eps], call)
+    # well-conditioned weights (final layer gain 1): the reference's own fp32-vs-fp64
+    # noise on log_prob is ~2e-6 relative, so the 1e-5 north-star bound is meaningful
+    ents, ints, o32, o64, _ = run_module_case(C3Stack, 501, [x, ctx, eps], call, final_gain=1.0)
     pack(out, "c3", ents, ints, ["lp_z", "lp", "lp_lds", "s_z", "s_logq", "s_lds"], o32, o64)
+    # stress weights (gain 6): derivatives hit the 1e-3 floor, the reference's fp32 run is
+    # itself up to 0.3 away from fp64 in log_prob; checked with the noise-aware criterion
+    ents, ints, o32, o64, _ = run_module_case(C3Stack, 501, [x, ctx, eps], call, final_gain=6.0)
+    keep = [0, 1, 3, 4]
+    pack(out, "c3_stress", ents, {}, ["lp_z", "lp", "s_z", "s_logq"], [o32[i] for i in keep], [o64[i] for i in keep])
     out["x"], out["ctx"], out["eps"] = npy(x), npy(ctx), npy(eps)
     save("g5_c3_stack", **out)
 
@@ -410,7 +417,7 @@ def g12_c2_tabular():
             z, ld = f(z)
             log_q -= ld
         return (lp, z, log_q)
-    ents, ints, o32, o64, _ = run_module_case(build, 1201, [x, eps], call)
+    ents, ints, o32, o64, _ = run_module_case(build, 1201, [x, eps], call, weight_gain=0.4)
     pack(out, "c2", ents, ints, ["lp", "s_z", "s_logq"], o32, o64)
     out["x"], out["eps"] = npy(x), npy(eps)
     save("g12_c2_tabular", **out)

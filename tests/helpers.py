@@ -22,11 +22,11 @@ def T(a, dtype=None):
     return t if dtype is None else t.to(dtype)
 
 
-def state_for(fx, tag, seed, dtype=torch.float32):
+def state_for(fx, tag, seed, dtype=torch.float32, final_gain=6.0, weight_gain=1.0):
     """Rebuild the state dict of fixture case ``tag``: synthetic float entries
     (same PCG64 stream as the generator) + stored integer buffers."""
     ents = synth.decode_entries(fx[tag + "/entries"])
-    sd = {k: v.to(dtype) for k, v in synth.synth_state(ents, seed).items()}
+    sd = {k: v.to(dtype) for k, v in synth.synth_state(ents, seed, final_gain, weight_gain).items()}
     pre = tag + "/int/"
     for k, v in fx.items():
         if k.startswith(pre):
@@ -77,19 +77,51 @@ def assert_close(got, want, rtol, atol, what=""):
         what, int(bad.sum()), g.numel(), float(err.max()), float(tol[err.argmax()]))
 
 
-def within_reference_noise(got, ref32, ref64, slack=2.0, floor=1e-6, what=""):
+def within_reference_noise(got, ref32, ref64, slack=2.0, max_slack=4.0, floor=1e-6, what=""):
     """the build must be no worse than the reference's own fp32
-    error: |got - ref64| <= slack*|ref32 - ref64| + floor*(1+|ref64|) elementwise
-    is too strict per element (a different rounding order moves single elements),
-    so the bound is applied to the distribution: max and mean error of the build
-    may not exceed slack x the reference's max / mean fp32 error plus floor."""
+    error.  |got - ref64| <= slack*|ref32 - ref64| elementwise is too strict (a
+    different rounding order moves single ill-conditioned elements), so the bound
+    is applied to the error distribution relative to the fp64 result: the build's
+    mean error may not exceed slack x the reference's mean fp32 error, and its
+    worst element max_slack x the reference's worst element (plus floor)."""
     got = got.detach().cpu().double()
     r32, r64 = torch.as_tensor(ref32).double(), torch.as_tensor(ref64).double()
     ok = torch.isfinite(r64) & torch.isfinite(got)
+    if int(ok.sum()) < 2048:
+        return          # too few elements for a statistical comparison; elementwise bounds cover these
     scale = 1.0 + r64[ok].abs()
     e_build = ((got[ok] - r64[ok]).abs() / scale)
     e_ref = ((r32[ok] - r64[ok]).abs() / scale)
-    assert e_build.max() <= slack * e_ref.max() + floor, "%s max err %.3e vs ref fp32 %.3e" % (
+    assert e_build.max() <= max_slack * e_ref.max() + floor, "%s max err %.3e vs ref fp32 %.3e" % (
         what, float(e_build.max()), float(e_ref.max()))
     assert e_build.mean() <= slack * e_ref.mean() + floor, "%s mean err %.3e vs ref fp32 %.3e" % (
         what, float(e_build.mean()), float(e_ref.mean()))
+
+
+def parity(got, ref32, ref64, rtol=2e-5, atol=2e-5, what="", noise_floor=0.0):
+    """Parity of an fp32 result with the reference's fp32 output, aware of the
+    reference's own rounding noise (its fp32 run vs its fp64 run on the fixture):
+      1. identical NaN pattern;
+      2. elementwise |got - ref32| <= atol + rtol*|ref32| + 8 * max|ref32 - ref64|
+         (on well-conditioned fixtures the last term vanishes and this is a plain
+         tight comparison; on ill-conditioned ones it scales with the noise);
+      3. against fp64 the build is no worse than the reference's fp32 run
+         (within_reference_noise)."""
+    g = got.detach().cpu().double()
+    r32 = torch.as_tensor(np.asarray(ref32)).double()
+    r64 = torch.as_tensor(np.asarray(ref64)).double()
+    assert g.shape == r32.shape, "%s shape %s vs %s" % (what, tuple(g.shape), tuple(r32.shape))
+    assert torch.equal(torch.isnan(g), torch.isnan(r32)), "%s NaN pattern differs" % what
+    ok = torch.isfinite(r32) & torch.isfinite(r64) & torch.isfinite(g)
+    assert torch.equal(torch.isfinite(g), torch.isfinite(r32)), "%s inf pattern differs" % what
+    if not ok.any():
+        return
+    # noise_floor: noise level measured on a larger sample of the same configuration
+    # (a 1-row batch can have an accidentally exact reference)
+    noise = max(float((r32[ok] - r64[ok]).abs().max()), float(noise_floor))
+    err = (g[ok] - r32[ok]).abs()
+    tol = atol + rtol * r32[ok].abs() + 8.0 * noise
+    bad = err > tol
+    assert not bad.any(), "%s: %d/%d outside tol, max err %.3e (tol there %.3e, ref noise %.3e)" % (
+        what, int(bad.sum()), int(ok.sum()), float(err.max()), float(tol[err.argmax()]), noise)
+    within_reference_noise(got, ref32, ref64, what=what)

@@ -1,0 +1,566 @@
+"""Parity of the HIP path (called through the C ABI via vcnf_amd) against the
+reference's golden vectors and against the CPU oracle on fresh seeded inputs.
+
+Tolerances (fp32 kernels vs the reference's fp32 AND fp64 outputs, helpers.parity):
+  * every float result: |got - ref32| <= 2e-5 + 2e-5*|ref32| + 8*noise, where noise
+    = max|ref32 - ref64| is the reference's own fp32 rounding noise on that fixture
+    (0 for well-conditioned cases, up to 4e-3 for single splines with randn-scale
+    logits, whose tiny bins / floor-level derivatives amplify rounding), and against
+    fp64 the build's mean / max error stays within 2x / 4x the reference's own;
+  * north star: on the well-conditioned C3 fixture (reference noise ~2e-6 relative)
+    per-sample log_prob and sample log_q satisfy |got - ref32| <= 1e-5*|ref32| + 2e-5
+    with no noise allowance (test_g5_c3_stack_log_prob_and_sample);
+  * integer / index items and pure copies: bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+import vcnf_amd as nf
+from vcnf_amd import _lib
+from helpers import (fixture, T, state_for, assert_close, within_reference_noise, parity,
+                     oracle_rqs_coupling, oracle_c3_stack, oracle_affine_stack)
+from oracle import rqs as OR, layers as OL, nets as ON
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=2e-5, atol=2e-5)
+LP = dict(rtol=1e-5, atol=2e-5)
+
+
+def dev(t):
+    return t.cuda()
+
+
+def load(module, sd):
+    module.load_state_dict(sd, strict=True)
+    return module.cuda().eval()
+
+
+# ---------------------------------------------------------------- splines (G1, G2)
+@pytest.mark.parametrize("k", [8, 10, 16])
+@pytest.mark.parametrize("inv", [False, True])
+def test_g1_rational_quadratic_spline(hip, k, inv):
+    fx = fixture("g1_rqs")
+    a = [dev(T(fx["K%d/%s" % (k, n)])) for n in ("x", "uw", "uh", "ud")]
+    with torch.no_grad():
+        y, ld = nf.utils.splines.rational_quadratic_spline(*a, inverse=inv)
+    tag = "K%d_%s" % (k, "inv" if inv else "fwd")
+    parity(y, fx[tag + "/y32"], fx[tag + "/y64"], what=tag + " y")
+    parity(ld, fx[tag + "/ld32"], fx[tag + "/ld64"], what=tag + " ld")
+
+
+@pytest.mark.parametrize("case", ["K8_T3", "K8_T1", "K16_T5", "K5_T2.5"])
+@pytest.mark.parametrize("inv", [False, True])
+def test_g2_unconstrained_spline_tails(hip, case, inv):
+    fx = fixture("g2_rqs_tails")
+    tb = float(case.split("_T")[1])
+    a = [dev(T(fx["%s/%s" % (case, n)])) for n in ("x", "uw", "uh", "ud")]
+    with torch.no_grad():
+        y, ld = nf.utils.splines.unconstrained_rational_quadratic_spline(
+            *a, inverse=inv, tails="linear", tail_bound=tb)
+    tag = case + ("_inv" if inv else "_fwd")
+    parity(y, fx[tag + "/y32"], fx[tag + "/y64"], what=tag + " y")
+    parity(ld, fx[tag + "/ld32"], fx[tag + "/ld64"], what=tag + " ld")
+    # outside the interval: bit-exact identity and exactly zero log-det
+    x = fx[case + "/x"]
+    out = ~((x >= -tb) & (x <= tb))
+    assert out.any()
+    assert np.array_equal(y.cpu().numpy()[out], x[out])
+    assert np.all(ld.cpu().numpy()[out] == 0.0)
+
+
+def test_spline_round_trip_properties(hip):
+    """The reference's own test (utils/splines_test.py:6-56): inverse(forward(x))
+    == x and the two log-dets cancel, eps 1e-4 - on its shape [2,3,4] with K=10.
+    Larger random draws contain ill-conditioned elements (tiny bins, floor-level
+    derivatives) where fp32 cannot hold 1e-4; there the bound is the oracle's own
+    fp32 round-trip error on the same inputs (x4) plus 1e-4."""
+    g = torch.Generator().manual_seed(5)
+    for shape, k in (((2, 3, 4), 10), ((1000, 7), 8), ((5,), 3)):
+        uw = torch.randn(*shape, k, generator=g)
+        uh = torch.randn(*shape, k, generator=g)
+        ud = torch.randn(*shape, k + 1, generator=g)
+        x = torch.rand(*shape, generator=g)
+        oy, old_ = OR.rq_spline(x, uw, uh, ud)
+        oxr, oldi = OR.rq_spline(oy, uw, uh, ud, inverse=True)
+        tol_x = 1e-4 + 4 * float((oxr - x).abs().max())
+        tol_l = 1e-4 + 4 * float((old_ + oldi).abs().max())
+        with torch.no_grad():
+            y, ld = nf.utils.splines.rational_quadratic_spline(dev(x), dev(uw), dev(uh), dev(ud))
+            xr, ldi = nf.utils.splines.rational_quadratic_spline(y, dev(uw), dev(uh), dev(ud), inverse=True)
+        assert y.shape == x.shape and torch.isfinite(y).all() and torch.isfinite(ld).all()
+        assert_close(xr, x, rtol=0, atol=tol_x, what="round trip")
+        assert_close(ld + ldi, torch.zeros(shape), rtol=0, atol=tol_l, what="log-det cancel")
+        udl = torch.randn(*shape, k - 1, generator=g)
+        x3 = 3 * torch.randn(*shape, generator=g)
+        oy, old_ = OR.rq_spline_tails(x3, uw, uh, udl, tail_bound=1.0)
+        oxr, oldi = OR.rq_spline_tails(oy, uw, uh, udl, inverse=True, tail_bound=1.0)
+        tol_x = 1e-4 + 4 * float((oxr - x3).abs().max())
+        tol_l = 1e-4 + 4 * float((old_ + oldi).abs().max())
+        with torch.no_grad():
+            y, ld = nf.utils.splines.unconstrained_rational_quadratic_spline(
+                dev(x3), dev(uw), dev(uh), dev(udl), tail_bound=1.0)
+            xr, ldi = nf.utils.splines.unconstrained_rational_quadratic_spline(
+                y, dev(uw), dev(uh), dev(udl), inverse=True, tail_bound=1.0)
+        assert_close(xr, x3, rtol=0, atol=tol_x, what="tails round trip")
+        assert_close(ld + ldi, torch.zeros(shape), rtol=0, atol=tol_l, what="tails log-det cancel")
+    nf.check_discriminant()
+
+
+def test_spline_generic_bin_counts_vs_oracle(hip):
+    """K values without a compile-time specialisation go through the runtime-K path."""
+    g = torch.Generator().manual_seed(6)
+    for k in (2, 3, 5, 7, 12, 24, 33):
+        uw, uh = torch.randn(300, k, generator=g), torch.randn(300, k, generator=g)
+        ud = torch.randn(300, k - 1, generator=g)
+        x = 2.5 * torch.randn(300, generator=g)
+        for inv in (False, True):
+            want_y, want_ld = OR.rq_spline_tails(x.double(), uw.double(), uh.double(), ud.double(),
+                                                 inverse=inv, tail_bound=2.0)
+            with torch.no_grad():
+                y, ld = nf.utils.splines.unconstrained_rational_quadratic_spline(
+                    dev(x), dev(uw), dev(uh), dev(ud), inverse=inv, tail_bound=2.0)
+            assert_close(y, want_y, rtol=1e-4, atol=1e-4, what="K=%d y" % k)
+            assert_close(ld, want_ld, rtol=1e-3, atol=1e-3, what="K=%d ld" % k)
+
+
+# ---------------------------------------------------------------- RQS coupling layers (G3, G4)
+@pytest.mark.parametrize("rm", [0, 1])
+def test_g3_coupled_rqs_layer(hip, rm):
+    fx = fixture("g3_crqs_layer")
+    sd, _ = state_for(fx, "rm%d" % rm, 301 + rm, final_gain=2.0)
+    m = load(nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8, reverse_mask=bool(rm)), sd)
+    x = dev(T(fx["x"]))
+    pre = "rm%d/" % rm
+    with torch.no_grad():
+        z, ld = m.inverse(x)
+        parity(z, fx[pre + "inv_z32"], fx[pre + "inv_z64"], what="inverse z")
+        parity(ld, fx[pre + "inv_ld32"], fx[pre + "inv_ld64"], what="inverse ld")
+        z, ld = m.forward(x)
+        parity(z, fx[pre + "fwd_z32"], fx[pre + "fwd_z64"], what="forward z")
+        parity(ld, fx[pre + "fwd_ld32"], fx[pre + "fwd_ld64"], what="forward ld")
+        assert ld.shape == (256,)
+    nf.check_discriminant()
+
+
+def _cond_layer(tag, fx):
+    d, c, h, nb, k, tb, kind = fx[tag + "/cfg"]
+    d, c, h, nb, k = int(d), int(c), int(h), int(nb), int(k)
+    mask = (nf.utils.create_alternating_binary_mask(d, even=False) if kind == 0
+            else nf.utils.create_mid_split_binary_mask(d))
+    net = lambda i, o: nf.nets.ResidualNet(i, o, hidden_features=h, context_features=c, num_blocks=nb)
+    m = nf.flows.PiecewiseRationalQuadraticCoupling(mask, net, num_bins=k, tails="linear", tail_bound=float(tb),
+                                                    apply_unconditional_transform=True)
+    sd, _ = state_for(fx, tag, 401 + d, final_gain=2.0)
+    return load(m, sd), d
+
+
+@pytest.mark.parametrize("tag", ["d64", "d21", "d7k4"])
+def test_g4_conditional_coupling(hip, tag):
+    fx = fixture("g4_cond_prqc")
+    m, d = _cond_layer(tag, fx)
+    x, ctx = dev(T(fx[tag + "/x"])), dev(T(fx[tag + "/ctx"]))
+    with torch.no_grad():
+        z, ld = m.forward(x, ctx)
+        parity(z, fx[tag + "/nsf_fwd_z32"], fx[tag + "/nsf_fwd_z64"], what="nsf forward z")
+        parity(ld, fx[tag + "/nsf_fwd_ld32"], fx[tag + "/nsf_fwd_ld64"], what="nsf forward ld")
+        z, ld = m.inverse(x, ctx)
+        parity(z, fx[tag + "/nsf_inv_z32"], fx[tag + "/nsf_inv_z64"], what="nsf inverse z")
+        parity(ld, fx[tag + "/nsf_inv_ld32"], fx[tag + "/nsf_inv_ld64"], what="nsf inverse ld")
+    nf.check_discriminant()
+
+
+def test_coupling_properties(hip):
+    """flows/neural_spline/coupling_test.py of the reference restated: shape and
+    finiteness, identity features untouched without the unconditional transform
+    and changed with it, round trip <= 1e-4."""
+    torch.manual_seed(3)
+    for d in (20, 7, 2):
+        mask = nf.utils.create_mid_split_binary_mask(d)
+        for uncond in (False, True):
+            net = lambda i, o: nf.nets.ResidualNet(i, o, hidden_features=30, num_blocks=5)
+            m = nf.flows.PiecewiseRationalQuadraticCoupling(mask, net, tails="linear", tail_bound=2.0,
+                                                            apply_unconditional_transform=uncond).cuda()
+            if uncond:
+                with torch.no_grad():
+                    for p in m.unconditional_transform.parameters():
+                        p.normal_(0, 0.5)
+            x = dev(torch.randn(10, d))
+            with torch.no_grad():
+                y, ld = m(x)
+                xr, ldi = m.inverse(y)
+            assert y.shape == x.shape and ld.shape == (10,)
+            assert torch.isfinite(y).all() and torch.isfinite(ld).all()
+            idf = (mask <= 0).cuda()
+            if uncond:
+                assert not torch.equal(y[:, idf], x[:, idf])
+            else:
+                assert torch.equal(y[:, idf], x[:, idf])          # bit-exact pass-through
+            assert_close(xr, x.cpu(), rtol=0, atol=1e-4, what="round trip d=%d" % d)
+            assert_close(ld + ldi, torch.zeros(10), rtol=0, atol=1e-4, what="log-det cancel")
+
+
+def test_conditioner_input_matches_kernel_output(hip):
+    """Sampling direction: the identity values handed to the conditioner and the
+    ones written to the output come from two kernels and must agree bitwise."""
+    fx = fixture("g4_cond_prqc")
+    m, d = _cond_layer("d64", fx)
+    x, ctx = dev(T(fx["d64/x"])), dev(T(fx["d64/ctx"]))
+    with torch.no_grad():
+        first = _lib.rqs_conditioner_input(x, m._index32('id'), ctx, m.unconditional_transform.logits(),
+                                           m._cfg(False), True)
+        y, _ = m.inverse(x, ctx)
+    assert torch.equal(first[:, :32], y[:, m.identity_features])
+    assert torch.equal(first[:, 32:], ctx)
+
+
+# ---------------------------------------------------------------- C3 stack (G5)
+def _c3_model(layers=12, d=64, c=16, hidden=128, blocks=2, k=8):
+    flows = [nf.flows.CoupledRationalQuadraticSpline(d, blocks, hidden, k, reverse_mask=bool(i % 2),
+                                                     num_context_channels=c) for i in range(layers)]
+    return nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows)
+
+
+def test_g5_c3_stack_log_prob_and_sample(hip):
+    """North-star parity: config C3's stack on the well-conditioned fixture."""
+    fx = fixture("g5_c3_stack")
+    sd, _ = state_for(fx, "c3", 501, final_gain=1.0)
+    model = load(_c3_model(), sd)
+    x, ctx, eps = (dev(T(fx[n])) for n in ("x", "ctx", "eps"))
+    with torch.no_grad():
+        lp = model.log_prob(x, ctx)
+        assert_close(lp, fx["c3/lp32"], what="log_prob (1e-5 rel)", **LP)
+        within_reference_noise(lp, fx["c3/lp32"], fx["c3/lp64"], what="log_prob vs fp64")
+        z, lq = model.sample_from(eps, ctx)
+        parity(z, fx["c3/s_z32"], fx["c3/s_z64"], what="sample z")
+        parity(lq, fx["c3/s_logq32"], fx["c3/s_logq64"], rtol=1e-5, atol=2e-5, what="sample log_q")
+        # inverse reconstruction: the density pass maps the sampled z back onto the base noise
+        zz, lds = z, []
+        for f in reversed(model.flows):
+            zz, ld = f.inverse(zz, context=ctx)
+        rec = (zz.cpu() - (eps.cpu() * torch.exp(model.q0.log_scale.cpu()) + model.q0.loc.cpu())).abs()
+        assert float(rec.mean()) < 5e-5 and float(rec.max()) < 2e-2, (float(rec.mean()), float(rec.max()))
+        # layer by layer through the plain Flow contract (no in-kernel accumulation)
+        zz, lds = x, []
+        for f in reversed(model.flows):
+            zz, ld = f.inverse(zz, context=ctx)
+            lds.append(ld)
+        parity(torch.stack(lds), fx["c3/lp_lds32"], fx["c3/lp_lds64"], what="per-layer log_dets")
+        parity(zz, fx["c3/lp_z32"], fx["c3/lp_z64"], what="latent")
+    nf.check_discriminant()
+
+
+def test_g5_c3_stack_stress_weights(hip):
+    """Same stack with wild conditioner logits (derivatives at the 1e-3 floor): the
+    reference's own fp32 log_prob is up to 0.3 away from fp64 here; the build must
+    stay inside that noise envelope."""
+    fx = fixture("g5_c3_stack")
+    sd, _ = state_for(fx, "c3_stress", 501, final_gain=6.0)
+    sd.update({k[len("c3/int/"):]: T(v) for k, v in fx.items() if k.startswith("c3/int/")})
+    model = load(_c3_model(), sd)
+    x, ctx, eps = (dev(T(fx[n])) for n in ("x", "ctx", "eps"))
+    with torch.no_grad():
+        parity(model.log_prob(x, ctx), fx["c3_stress/lp32"], fx["c3_stress/lp64"], what="log_prob")
+        z, lq = model.sample_from(eps, ctx)
+        parity(z, fx["c3_stress/s_z32"], fx["c3_stress/s_z64"], what="sample z")
+        parity(lq, fx["c3_stress/s_logq32"], fx["c3_stress/s_logq64"], what="sample log_q")
+    nf.check_discriminant()
+
+
+# ---------------------------------------------------------------- affine (G6), masked affine (G7)
+@pytest.mark.parametrize("d", [2, 32, 33])
+@pytest.mark.parametrize("sm", ["exp", "sigmoid", "sigmoid_inv", "noscale"])
+@pytest.mark.parametrize("mode", ["channel", "channel_inv"])
+def test_g6_affine_coupling_block(hip, d, sm, mode):
+    fx = fixture("g6_affine")
+    tag = "d%d/%s/%s" % (d, sm, mode)
+    d1 = (d + 1) // 2
+    cin, cout = (d1, d - d1) if mode == "channel" else (d - d1, d1)
+    scale = sm != "noscale"
+    blk = nf.flows.AffineCouplingBlock(nf.nets.MLP([cin, 24, 24, (2 if scale else 1) * cout]), scale=scale,
+                                       scale_map=sm if scale else "exp", split_mode=mode)
+    sd, _ = state_for(fx, tag, 601 + d)
+    blk = load(blk, sd)
+    x = dev(T(fx["d%d/x" % d]))
+    with torch.no_grad():
+        for dirn, fn in (("fwd", blk.forward), ("inv", blk.inverse)):
+            z, ld = fn(x.clone())
+            assert_close(z, fx["%s/%s_z32" % (tag, dirn)], what=dirn + " z", **TOL)
+            assert_close(ld, fx["%s/%s_ld32" % (tag, dirn)], what=dirn + " ld", **TOL)
+        # the unfused composition Split -> AffineCoupling -> Merge gives the same numbers
+        pair, _ = blk.flows[0](x.clone())
+        pair, ld2 = blk.flows[1](pair)
+        z2, _ = blk.flows[2](pair)
+        assert_close(z2, fx[tag + "/fwd_z32"], what="composed z", **TOL)
+
+
+@pytest.mark.parametrize("d", [2, 9, 30])
+@pytest.mark.parametrize("variant", ["st", "t_only", "s_only", "inf"])
+def test_g7_masked_affine_flow(hip, d, variant):
+    fx = fixture("g7_masked_affine")
+    tag = "d%d/%s" % (d, variant)
+    s = nf.nets.MLP([d, 16, d]) if variant != "t_only" else None
+    t = nf.nets.MLP([d, 16, d]) if variant != "s_only" else None
+    m = nf.flows.MaskedAffineFlow(T(fx["d%d/b" % d]), t, s)
+    sd, _ = state_for(fx, tag, 701 + d)
+    sd["b"] = T(fx["d%d/b" % d]).view(1, -1)
+    if variant == "inf":
+        sd["s.net.2.bias"][1] = float("inf")
+        sd["t.net.2.bias"][d - 1] = float("-inf")
+    m = load(m, sd)
+    x = dev(T(fx["d%d/x" % d]))
+    with torch.no_grad():
+        for dirn, fn in (("fwd", m.forward), ("inv", m.inverse)):
+            z, ld = fn(x)
+            assert_close(z, fx["%s/%s_z32" % (tag, dirn)], what=dirn + " z", **TOL)     # NaN pattern checked too
+            assert_close(ld, fx["%s/%s_ld32" % (tag, dirn)], what=dirn + " ld", **TOL)
+
+
+# ---------------------------------------------------------------- permutations (G8), Gaussian (G9)
+def test_g8_permute_bit_exact(hip):
+    fx = fixture("g8_indices")
+    for d in (2, 5, 32, 33):
+        x = dev(T(fx["swap/d%d/x" % d]))
+        p = nf.flows.Permute(d, mode="swap").cuda()
+        assert np.array_equal(p.forward(x)[0].cpu().numpy(), fx["swap/d%d/fwd" % d])
+        assert np.array_equal(p.inverse(x)[0].cpu().numpy(), fx["swap/d%d/inv" % d])
+    for d in (5, 64, 1024):
+        torch.manual_seed(7)
+        p = nf.flows.Permute(d, mode="shuffle").cuda()
+        x = torch.randn(33, d)
+        y = p.forward(dev(x))[0]
+        assert torch.equal(y.cpu(), x[:, torch.as_tensor(fx["perm/d%d_s7/perm" % d])])
+        assert torch.equal(p.inverse(y)[0].cpu(), x)
+    x4 = torch.randn(3, 6, 4, 5)
+    p = nf.flows.Permute(6, mode="swap").cuda()
+    assert torch.equal(p.forward(dev(x4))[0].cpu(), torch.cat([x4[:, 3:], x4[:, :3]], 1))
+
+
+@pytest.mark.parametrize("tag", ["d2_Tnone", "d64_Tnone", "d64_T0.7", "d33_T1.9"])
+def test_g9_diag_gaussian(hip, tag):
+    fx = fixture("g9_diag_gaussian")
+    d = int(tag[1:].split("_")[0])
+    temp = fx[tag + "/temp"][0]
+    q = nf.distributions.DiagGaussian(d)
+    sd, _ = state_for(fx, tag, 901 + d)
+    q = load(q, sd)
+    q.temperature = None if np.isnan(temp) else float(temp)
+    with torch.no_grad():
+        assert_close(q.log_prob(dev(T(fx[tag + "/z"]))), fx[tag + "/logp32"], what="log_prob", **TOL)
+        z, lp = q.from_noise(dev(T(fx[tag + "/eps32"])))
+        assert_close(z, fx[tag + "/s_z32"], what="sample z", **TOL)
+        assert_close(lp, fx[tag + "/s_logp32"], what="sample logp", **TOL)
+        z, lp = q(17)
+        assert z.shape == (17, d) and lp.shape == (17,)
+
+
+# ---------------------------------------------------------------- affine stacks C1 / C2 (G10, G12)
+def _affine_model(layers, d, widths):
+    flows = []
+    for _ in range(layers):
+        flows += [nf.flows.AffineCouplingBlock(nf.nets.MLP(widths)), nf.flows.Permute(d, mode="swap")]
+    return nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows)
+
+
+@pytest.mark.parametrize("name,tag,layers,d,widths,seed", [
+    ("g10_c1_two_moons", "c1", 4, 2, [1, 32, 32, 2], 1001),
+    ("g12_c2_tabular", "c2", 8, 32, [16, 64, 64, 32], 1201)])
+def test_affine_stacks_c1_c2(hip, name, tag, layers, d, widths, seed):
+    fx = fixture(name)
+    sd, _ = state_for(fx, tag, seed, weight_gain=0.4 if tag == "c2" else 1.0)
+    model = load(_affine_model(layers, d, widths), sd)
+    with torch.no_grad():
+        lp = model.log_prob(dev(T(fx["x"])))
+        assert_close(lp, fx[tag + "/lp32"], what="log_prob", **LP)
+        z, lq = model.sample_from(dev(T(fx["eps"])))
+        assert_close(z, fx[tag + "/s_z32"], what="sample z", **TOL)
+        assert_close(lq, fx[tag + "/s_logq32"], what="sample log_q", **LP)
+
+
+# ---------------------------------------------------------------- fresh inputs vs the oracle, ragged sizes
+def _oracle_pair(sd, prefix, k, tb, hid):
+    o32 = oracle_rqs_coupling(sd, prefix, k, tb, hid)
+    o64 = oracle_rqs_coupling({n: v.double() if v.is_floating_point() else v for n, v in sd.items()},
+                              prefix, k, tb, hid)
+    return o32, o64
+
+
+def _check_vs_oracle(m, o32, o64, x, ctx, what, noise=None):
+    """Both directions of a wrapper layer against the oracle run in fp32 and fp64.
+    Returns the oracle's fp32 noise per (direction, output) for reuse as a floor."""
+    seen = {}
+    with torch.no_grad():
+        for dirn in ("inverse", "forward"):
+            a32 = (x,) if ctx is None else (x, ctx)
+            a64 = tuple(t.double() for t in a32)
+            w32, l32 = getattr(o32, dirn)(*a32)
+            w64, l64 = getattr(o64, dirn)(*a64)
+            z, ld = getattr(m, dirn)(dev(x)) if ctx is None else getattr(m, dirn)(dev(x), context=dev(ctx))
+            nz, nl = (noise or {}).get(dirn, (0.0, 0.0))
+            parity(z, w32, w64, what="%s %s z" % (what, dirn), noise_floor=nz)
+            parity(ld, l32, l64, what="%s %s ld" % (what, dirn), noise_floor=nl)
+            seen[dirn] = (float((w32 - w64).abs().max()), float((l32 - l64).abs().max()))
+    return seen
+
+
+def test_c3_layer_vs_oracle_ragged_batches(hip):
+    """Batch sizes around the tile size (8 samples per workgroup pass), 1 row, and
+    a large odd size; the oracle's fp32 noise measured at B=4099 is the floor for
+    the tiny batches."""
+    fx = fixture("g5_c3_stack")
+    sd, _ = state_for(fx, "c3", 501, final_gain=2.0)
+    sub = {k: v for k, v in sd.items() if k.startswith("flows.0.")}
+    m = load(nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8, num_context_channels=16),
+             {k[len("flows.0."):]: v for k, v in sub.items()})
+    o32, o64 = _oracle_pair(sub, "flows.0.prqct.", 8, 3.0, 128)
+    noise = None
+    for batch in (4099, 257, 9, 8, 7, 3, 1):
+        g = torch.Generator().manual_seed(batch)
+        x, ctx = 1.2 * torch.randn(batch, 64, generator=g), torch.randn(batch, 16, generator=g)
+        seen = _check_vs_oracle(m, o32, o64, x, ctx, "B=%d" % batch, noise)
+        noise = noise or seen
+
+
+def test_empty_batch(hip):
+    m = nf.flows.CoupledRationalQuadraticSpline(8, 1, 16).cuda()
+    blk = nf.flows.AffineCouplingBlock(nf.nets.MLP([4, 8, 8])).cuda()
+    with torch.no_grad():
+        z, ld = m.inverse(torch.empty(0, 8, device="cuda"))
+        assert z.shape == (0, 8) and ld.shape == (0,)
+        z, ld = blk.forward(torch.empty(0, 8, device="cuda"))
+        assert z.shape == (0, 8) and ld.shape == (0,)
+
+
+def test_wide_layer_chunked_params_vs_oracle(hip):
+    """D=1024, K=16 (config C5's layer shape): the params tile does not fit LDS
+    whole, the kernel streams it in feature chunks and the unconditional spline
+    reads its logits from L2 instead of LDS tables."""
+    torch.manual_seed(9)
+    d, k, h = 1024, 16, 32
+    m = nf.flows.CoupledRationalQuadraticSpline(d, 1, h, k).cuda()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "unnormalized" in n:
+                p.normal_(0, 0.5)
+            elif "final_layer.weight" in n:
+                p.normal_(0, 6.0 / np.sqrt(h))
+    sd = {k_: v.detach().cpu() for k_, v in m.state_dict().items()}
+    o32, o64 = _oracle_pair(sd, "prqct.", k, 3.0, h)
+    _check_vs_oracle(m, o32, o64, 1.3 * torch.randn(37, d), None, "D=1024")
+    nf.check_discriminant()
+
+
+def test_odd_shapes_vs_oracle(hip):
+    """Odd feature counts, even P (bank-conflicting stride), unaligned row lengths."""
+    torch.manual_seed(10)
+    for d, k, hid in ((3, 5, 8), (11, 7, 16), (33, 4, 8), (2, 8, 8), (130, 10, 16)):
+        for rm in (False, True):
+            m = nf.flows.CoupledRationalQuadraticSpline(d, 1, hid, k, tail_bound=2.0, reverse_mask=rm).cuda()
+            with torch.no_grad():
+                for n, p in m.named_parameters():
+                    if "unnormalized" in n:
+                        p.normal_(0, 0.5)
+                    elif "final_layer.weight" in n:
+                        p.normal_(0, 2.0 / np.sqrt(hid))
+            sd = {k_: v.detach().cpu() for k_, v in m.state_dict().items()}
+            o32, o64 = _oracle_pair(sd, "prqct.", k, 2.0, hid)
+            _check_vs_oracle(m, o32, o64, 1.2 * torch.randn(101, d), None, "d=%d K=%d" % (d, k))
+
+
+def test_affine_image_shaped_vs_oracle(hip):
+    """4-D inputs (Glow family, config C4's coupling): channel split with a conv
+    conditioner, sigmoid scale map, reduction over all non-batch dims."""
+    torch.manual_seed(12)
+    for c, hw, mode in ((12, 4, "channel"), (7, 3, "channel_inv"), (4, 8, "channel")):
+        head = c - c // 2
+        cin, cout = (head, c - head) if mode == "channel" else (c - head, head)
+        conv = torch.nn.Sequential(torch.nn.Conv2d(cin, 8, 3, padding=1), torch.nn.LeakyReLU(0.0),
+                                   torch.nn.Conv2d(8, 2 * cout, 3, padding=1))
+        blk = nf.flows.AffineCouplingBlock(conv, scale_map="sigmoid", split_mode=mode).cuda()
+        conv64 = torch.nn.Sequential(torch.nn.Conv2d(cin, 8, 3, padding=1), torch.nn.LeakyReLU(0.0),
+                                     torch.nn.Conv2d(8, 2 * cout, 3, padding=1)).double()
+        conv64.load_state_dict({k: v.detach().cpu().double() for k, v in conv.state_dict().items()})
+        ora = OL.AffineCouplingBlock(lambda z: conv64(z), scale_map="sigmoid", split_mode=mode)
+        x = torch.randn(5, c, hw, hw)
+        with torch.no_grad():
+            for dirn in ("forward", "inverse"):
+                want_z, want_ld = getattr(ora, dirn)(x.double())
+                z, ld = getattr(blk, dirn)(dev(x))
+                assert_close(z, want_z, what="%s z" % dirn, rtol=1e-5, atol=1e-5)
+                assert_close(ld, want_ld, what="%s ld" % dirn, rtol=1e-5, atol=1e-4)
+
+
+def test_affine_const_flow_vs_oracle(hip):
+    torch.manual_seed(13)
+    for shape, zshape in (((6,), (9, 6)), ((5, 1, 1), (4, 5, 3, 3))):
+        m = nf.flows.AffineConstFlow(shape).cuda()
+        with torch.no_grad():
+            m.s.normal_(0, 0.3)
+            m.t.normal_(0, 0.3)
+        ora = OL.AffineConst(m.s.detach().cpu().double(), m.t.detach().cpu().double())
+        x = torch.randn(*zshape)
+        with torch.no_grad():
+            for dirn in ("forward", "inverse"):
+                want_z, want_ld = getattr(ora, dirn)(x.double())
+                z, ld = getattr(m, dirn)(dev(x))
+                assert_close(z, want_z, what=dirn + " z", rtol=1e-5, atol=1e-5)
+                assert_close(ld, want_ld, what=dirn + " ld", rtol=1e-5, atol=1e-5)
+
+
+def test_requires_grad_is_refused(hip):
+    m = nf.flows.CoupledRationalQuadraticSpline(8, 1, 16).cuda()
+    with pytest.raises(NotImplementedError):
+        m.inverse(torch.randn(4, 8, device="cuda"))     # grad mode on, weights require grad
+    with pytest.raises(NotImplementedError):
+        nf.NormalizingFlow(nf.distributions.DiagGaussian(8), [m]).forward_kld(torch.randn(4, 8, device="cuda"))
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE configs)
+def test_c3_full_size_round_trip(hip):
+    """Config C3 at the benchmark batch (1M x 64, 12 layers, context 16): sample
+    then log_prob must reproduce log_q and the base noise (size-independent
+    properties; the oracle cannot run this size in seconds)."""
+    torch.manual_seed(0)
+    model = _c3_model().cuda().eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "unnormalized" in n:
+                p.normal_(0, 0.5)
+    b = 1 << 20
+    eps = torch.randn(b, 64, device="cuda")
+    ctx = torch.randn(b, 16, device="cuda")
+    with torch.no_grad():
+        z, lq = model.sample_from(eps, ctx)
+        lp = model.log_prob(z, ctx)
+        assert torch.isfinite(z).all() and torch.isfinite(lq).all()
+        err = (lp - lq).abs() / (1.0 + lq.abs())
+        print("C3 1M round trip: log_q rel err max %.3e mean %.3e" % (float(err.max()), float(err.mean())))
+        # worst element of 8e8 spline evaluations sits in a floor-derivative bin; the mean is the tight bound
+        assert float(err.max()) < 2e-2, float(err.max())
+        assert float(err.mean()) < 5e-5, float(err.mean())
+        # base noise recovered by walking the flows backwards
+        zz = z
+        for f in reversed(model.flows):
+            zz, _ = f.inverse(zz, context=ctx)
+        rec = (zz - eps).abs()
+        print("C3 1M reconstruction: |z0 - eps| max %.3e mean %.3e" % (float(rec.max()), float(rec.mean())))
+        assert float(rec.max()) < 5e-2 and float(rec.mean()) < 1e-5, (float(rec.max()), float(rec.mean()))
+        # linearity of the log_q accumulation: accumulating into a non-zero buffer adds exactly
+        part = model.flows[0].inverse(z[:4096], context=ctx[:4096])[1]
+        acc = torch.full((4096,), 2.5, device="cuda")
+        model.flows[0].inverse_into(z[:4096], acc, context=ctx[:4096])
+        assert_close(acc - 2.5, part.cpu(), rtol=1e-6, atol=1e-5, what="accumulate")
+    nf.check_discriminant()
+
+
+def test_c2_full_size_round_trip(hip):
+    torch.manual_seed(1)
+    model = _affine_model(8, 32, [16, 64, 64, 32]).cuda().eval()
+    b = 262144
+    eps = torch.randn(b, 32, device="cuda")
+    with torch.no_grad():
+        z, lq = model.sample_from(eps)
+        lp = model.log_prob(z)
+        err = (lp - lq).abs() / (1.0 + lq.abs())
+        assert float(err.max()) < 1e-5, float(err.max())

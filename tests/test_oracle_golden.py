@@ -49,7 +49,7 @@ def test_g2_rq_spline_tails(case, inv):
 def test_g3_crqs_layer(rm):
     fx = fixture("g3_crqs_layer")
     for dt, suf, tol in ((torch.float32, "32", F32), (torch.float64, "64", F64)):
-        sd, _ = state_for(fx, "rm%d" % rm, 301 + rm, dt)
+        sd, _ = state_for(fx, "rm%d" % rm, 301 + rm, dt, final_gain=2.0)
         lay = oracle_rqs_coupling(sd, "prqct.", 8, 3.0, 128)
         x = T(fx["x"], dt)
         z, ld = lay.inverse(x)
@@ -65,7 +65,7 @@ def test_g4_conditional_coupling(tag):
     fx = fixture("g4_cond_prqc")
     d, c, h, nb, k, tb, kind = fx[tag + "/cfg"]
     for dt, suf, tol in ((torch.float32, "32", F32), (torch.float64, "64", F64)):
-        sd, _ = state_for(fx, tag, 401 + int(d), dt)
+        sd, _ = state_for(fx, tag, 401 + int(d), dt, final_gain=2.0)
         lay = oracle_rqs_coupling(sd, "", int(k), float(tb), int(h))
         x, ctx = T(fx[tag + "/x"], dt), T(fx[tag + "/ctx"], dt)
         z, ld = lay.nsf_forward(x, ctx)
@@ -76,10 +76,23 @@ def test_g4_conditional_coupling(tag):
         assert_close(ld, fx[tag + "/nsf_inv_ld" + suf], what="inv ld", **tol)
 
 
+def test_g5_c3_stack_stress_weights():
+    fx = fixture("g5_c3_stack")
+    for dt, suf, tol in ((torch.float32, "32", dict(rtol=1e-5, atol=2e-5)), (torch.float64, "64", F64)):
+        sd, _ = state_for(fx, "c3_stress", 501, dt, final_gain=6.0)
+        sd.update({k[len("c3/int/"):]: T(v) for k, v in fx.items() if k.startswith("c3/int/")})
+        st = oracle_c3_stack(sd)
+        x, ctx, eps = (T(fx[n], dt) for n in ("x", "ctx", "eps"))
+        assert_close(st.log_prob(x, ctx), fx["c3_stress/lp" + suf], what="log_prob", **tol)
+        z, lq = st.sample_from(eps, ctx)
+        assert_close(z, fx["c3_stress/s_z" + suf], what="sample z", **tol)
+        assert_close(lq, fx["c3_stress/s_logq" + suf], what="sample log_q", **tol)
+
+
 def test_g5_c3_stack():
     fx = fixture("g5_c3_stack")
     for dt, suf, tol in ((torch.float32, "32", dict(rtol=1e-5, atol=2e-5)), (torch.float64, "64", F64)):
-        sd, _ = state_for(fx, "c3", 501, dt)
+        sd, _ = state_for(fx, "c3", 501, dt, final_gain=1.0)
         st = oracle_c3_stack(sd)
         x, ctx, eps = (T(fx[n], dt) for n in ("x", "ctx", "eps"))
         tr = []
@@ -179,7 +192,7 @@ def test_g9_diag_gaussian(tag):
 def test_affine_stacks(name, tag, layers, d, seed):
     fx = fixture(name)
     for dt, suf, tol in ((torch.float32, "32", dict(rtol=1e-5, atol=1e-5)), (torch.float64, "64", F64)):
-        sd, ents = state_for(fx, tag, seed, dt)
+        sd, ents = state_for(fx, tag, seed, dt, weight_gain=0.4 if tag == "c2" else 1.0)
         st = oracle_affine_stack(sd, layers, d)
         lp = st.log_prob(T(fx["x"], dt))
         assert_close(lp, fx[tag + "/lp" + suf], what="log_prob", **tol)

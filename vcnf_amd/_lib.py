@@ -1,0 +1,336 @@
+"""ctypes binding of ``libvcnf_hip.so`` (the C ABI declared in include/vcnf_hip.h)
+and thin tensor-level wrappers around each entry point.
+
+There is no CPU implementation behind these wrappers: a CPU tensor, a missing
+library or a non-zero status raises.  PyTorch is used for device memory and the
+current HIP stream only.
+"""
+import ctypes
+import math
+import os
+
+import torch
+
+from . import build as _build
+
+_P = ctypes.c_void_p
+_I32, _I64, _F32, _INT = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_int
+
+OK = 0
+LD_STORE, LD_ACCUM = 0, 1
+TAILS_NONE, TAILS_LINEAR = 0, 1
+SCALE_EXP, SCALE_SIGMOID, SCALE_SIGMOID_INV, SCALE_NONE = 0, 1, 2, 3
+SCALE_MAPS = {"exp": SCALE_EXP, "sigmoid": SCALE_SIGMOID, "sigmoid_inv": SCALE_SIGMOID_INV}
+
+
+class RqsCfg(ctypes.Structure):
+    """struct vcnf_rqs_cfg"""
+    _fields_ = [("num_bins", _I32), ("tails", _I32), ("left", _F32), ("right", _F32),
+                ("bottom", _F32), ("top", _F32), ("min_bin_width", _F32),
+                ("min_bin_height", _F32), ("min_derivative", _F32), ("wh_scale", _F32)]
+
+
+# name -> argtypes, exactly the prototypes of include/vcnf_hip.h
+PROTOTYPES = {
+    "vcnf_abi_version": ([], _INT),
+    "vcnf_status_string": ([_INT], ctypes.c_char_p),
+    "vcnf_rqs_elementwise_f32": ([_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _I64,
+                                  ctypes.POINTER(RqsCfg), _INT, _P, _P], _INT),
+    "vcnf_rqs_coupling_f32": ([_P, _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _I64,
+                               ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P], _INT),
+    "vcnf_rqs_conditioner_input_f32": ([_P, _I64, _I32, _P, _I32, _P, _I32, _P, _P, _P,
+                                        ctypes.POINTER(RqsCfg), _INT, _P, _P], _INT),
+    "vcnf_affine_coupling_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _INT, _INT,
+                                  _INT, _F32, _P], _INT),
+    "vcnf_masked_affine_f32": ([_P, _P, _P, _P, _P, _P, _I64, _I32, _INT, _INT, _F32, _P], _INT),
+    "vcnf_affine_const_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _INT, _P], _INT),
+    "vcnf_permute_f32": ([_P, _P, _P, _I64, _I32, _I32, _P], _INT),
+    "vcnf_diag_gaussian_log_prob_f32": ([_P, _P, _P, _F32, _P, _I64, _I32, _INT, _F32, _P], _INT),
+    "vcnf_diag_gaussian_sample_f32": ([_P, _P, _P, _F32, _P, _P, _I64, _I32, _P], _INT),
+}
+
+_LIB = None
+
+
+class VcnfError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the library was not
+    built - there is no fallback path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise VcnfError("HIP library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(or python -m vcnf_amd.build); vcnf_amd has no CPU fallback" % path)
+    # torch ships its own libamdhip64 (soname libamdhip64.so.7); make sure that one is
+    # the HIP runtime our library binds to, so streams and pointers are shared with torch.
+    hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip_rt):
+        ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
+    handle = ctypes.CDLL(path)
+    for name, (args, res) in PROTOTYPES.items():
+        fn = getattr(handle, name)      # AttributeError if the ABI is incomplete
+        fn.argtypes, fn.restype = args, res
+    if handle.vcnf_abi_version() != 1:
+        raise VcnfError("libvcnf_hip.so ABI version mismatch")
+    _LIB = handle
+    return handle
+
+
+def _check(status, what):
+    if status != OK:
+        msg = lib().vcnf_status_string(status).decode()
+        if status == 4:       # splines.py:104-107 raises ValueError
+            raise ValueError(msg.capitalize())
+        raise VcnfError("%s: %s (status %d)" % (what, msg, status))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def require_device(*tensors):
+    """Every tensor must be an fp32 tensor on one HIP device; autograd through
+    the kernels is not available (VJP kernels: SURVEY 8f row 1)."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise VcnfError("vcnf_amd computes on MI355X only (tensor on %s); there is no CPU path" % t.device)
+        if t.is_floating_point() and t.dtype != torch.float32:
+            raise VcnfError("vcnf_amd kernels are fp32 (got %s)" % t.dtype)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise VcnfError("tensors on different devices: %s vs %s" % (dev, t.device))
+        if torch.is_grad_enabled() and t.requires_grad:
+            raise NotImplementedError(
+                "vcnf_amd: the HIP bijector kernels have no backward pass yet; evaluate under "
+                "torch.no_grad() (training path = SURVEY 8f row 1)")
+    return dev
+
+
+def make_cfg(num_bins, tails, tail_bound=1.0, left=0.0, right=1.0, bottom=0.0, top=1.0,
+             min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, wh_scale=1.0):
+    if tails == "linear":
+        left, right, bottom, top = -tail_bound, tail_bound, -tail_bound, tail_bound
+        mode = TAILS_LINEAR
+    elif tails is None:
+        mode = TAILS_NONE
+    else:
+        # circular tails / per-feature tail lists: SURVEY 8f row 4, not built
+        raise RuntimeError("{} tails are not implemented.".format(tails))
+    return RqsCfg(int(num_bins), mode, float(left), float(right), float(bottom), float(top),
+                  float(min_bin_width), float(min_bin_height), float(min_derivative), float(wh_scale))
+
+
+_BAD = {}
+
+# bench.py hook: when set to a list, rqs_coupling brackets its kernel launch with a
+# pair of HIP events on the launch stream and appends (start, end, batch) to it.
+EVENT_SINK = None
+
+
+def bad_discriminant_counter(device):
+    """Device int32 that the inverse spline kernels bump when b^2-4ac < 0 (the
+    reference asserts on the host, splines.py:164)."""
+    key = torch.device(device).index or 0
+    if key not in _BAD:
+        _BAD[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _BAD[key]
+
+
+def check_discriminant(device="cuda"):
+    """Host check (synchronises): raises AssertionError like splines.py:164 if an
+    inverse spline saw a negative discriminant since the last check."""
+    c = bad_discriminant_counter(torch.device(device))
+    n = int(c.item())
+    c.zero_()
+    assert n == 0, "negative discriminant in %d workgroup(s) of an inverse RQ spline" % n
+
+
+# ---------------------------------------------------------------- wrappers
+def rqs_elementwise(x, uw, uh, ud, cfg, inverse):
+    """x [...]; uw, uh [..., K]; ud [..., K-1 | K+1] (last dim contiguous)."""
+    dev = require_device(x, uw, uh, ud)
+    shape = x.shape
+    k = cfg.num_bins
+    nd = k - 1 if cfg.tails == TAILS_LINEAR else k + 1
+    if uw.shape != shape + (k,) or uh.shape != shape + (k,) or ud.shape != shape + (nd,):
+        raise VcnfError("spline parameter shapes %s %s %s do not match inputs %s with K=%d" % (
+            tuple(uw.shape), tuple(uh.shape), tuple(ud.shape), tuple(shape), k))
+    xf = x.reshape(-1).contiguous()
+
+    def rows(t, width):
+        t2 = t.reshape(-1, width)
+        if t2.stride(1) != 1 or (t2.shape[0] > 1 and t2.stride(0) < width):
+            t2 = t2.contiguous()
+        return t2, (t2.stride(0) if t2.shape[0] > 1 else width)
+    w2, ldw = rows(uw, k)
+    h2, ldh = rows(uh, k)
+    d2, ldd = rows(ud, nd)
+    y = torch.empty_like(xf)
+    lad = torch.empty_like(xf)
+    with torch.cuda.device(dev):
+        st = lib().vcnf_rqs_elementwise_f32(_ptr(xf), _ptr(w2), _ptr(h2), _ptr(d2), ldw, ldh, ldd,
+                                            _ptr(y), _ptr(lad), xf.numel(), ctypes.byref(cfg),
+                                            int(bool(inverse)),
+                                            _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
+    _check(st, "vcnf_rqs_elementwise_f32")
+    return y.view(shape), lad.view(shape)
+
+
+def rqs_coupling(x, params, tf_idx, id_idx, shared, cfg, inverse, logdet=None, sign=1.0):
+    """x [B,D] -> (y [B,D], logdet [B]).  ``logdet`` given: accumulate sign*sum
+    into it; else a fresh tensor holding sign*sum."""
+    dev = require_device(x, params, logdet, *(shared or ()))
+    b, d = x.shape
+    x = x.contiguous()
+    params = params.contiguous()
+    y = torch.empty_like(x)
+    mode = LD_ACCUM
+    if logdet is None:
+        logdet = torch.empty(b, dtype=torch.float32, device=dev)
+        mode = LD_STORE
+    sw, sh, sd = shared if shared is not None else (None, None, None)
+    sink = EVENT_SINK
+    with torch.cuda.device(dev):
+        if sink is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        st = lib().vcnf_rqs_coupling_f32(_ptr(x), _ptr(params), _ptr(tf_idx), tf_idx.numel(),
+                                         _ptr(id_idx), id_idx.numel(), _ptr(sw), _ptr(sh), _ptr(sd),
+                                         _ptr(y), _ptr(logdet), b, ctypes.byref(cfg), int(bool(inverse)),
+                                         mode, float(sign),
+                                         _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
+        if sink is not None:
+            ev1.record()
+            sink.append((ev0, ev1, b))
+    _check(st, "vcnf_rqs_coupling_f32")
+    return y, logdet
+
+
+def rqs_conditioner_input(x, id_idx, context, shared, cfg, apply_inverse_shared):
+    dev = require_device(x, context, *(shared or ()))
+    b, d = x.shape
+    x = x.contiguous()
+    c = 0
+    if context is not None:
+        context = context.contiguous()
+        c = context.shape[1]
+    out = torch.empty(b, id_idx.numel() + c, dtype=torch.float32, device=dev)
+    sw, sh, sd = shared if shared is not None else (None, None, None)
+    with torch.cuda.device(dev):
+        st = lib().vcnf_rqs_conditioner_input_f32(_ptr(x), b, d, _ptr(id_idx), id_idx.numel(), _ptr(context), c,
+                                                  _ptr(sw), _ptr(sh), _ptr(sd), ctypes.byref(cfg),
+                                                  int(bool(apply_inverse_shared)), _ptr(out), _stream())
+    _check(st, "vcnf_rqs_conditioner_input_f32")
+    return out
+
+
+def affine_coupling(z, param, t_off, d_t, scale_map, inverse, logdet=None, sign=1.0):
+    """z [B, C, *inner] -> (out, logdet [B] or None when scale_map is NONE and no
+    logdet was passed)."""
+    dev = require_device(z, param, logdet)
+    z = z.contiguous()
+    param = param.contiguous()
+    b, c = z.shape[0], z.shape[1]
+    inner = int(z[0, 0].numel()) if z.dim() > 2 else 1
+    out = torch.empty_like(z)
+    mode = LD_ACCUM
+    if logdet is None:
+        mode = LD_STORE
+        if scale_map != SCALE_NONE:
+            logdet = torch.empty(b, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = lib().vcnf_affine_coupling_f32(_ptr(z), _ptr(param), _ptr(out), _ptr(logdet), b, c, inner,
+                                            int(t_off), int(d_t), int(scale_map), int(bool(inverse)),
+                                            mode, float(sign), _stream())
+    _check(st, "vcnf_affine_coupling_f32")
+    return out, logdet
+
+
+def masked_affine(z, s, t, bmask, inverse, logdet=None, sign=1.0):
+    dev = require_device(z, s, t, bmask, logdet)
+    z = z.contiguous()
+    s = s.contiguous() if s is not None else None
+    t = t.contiguous() if t is not None else None
+    b, d = z.shape
+    out = torch.empty_like(z)
+    mode = LD_ACCUM
+    if logdet is None:
+        logdet = torch.empty(b, dtype=torch.float32, device=dev)
+        mode = LD_STORE
+    with torch.cuda.device(dev):
+        st = lib().vcnf_masked_affine_f32(_ptr(z), _ptr(s), _ptr(t), _ptr(bmask), _ptr(out), _ptr(logdet),
+                                          b, d, int(bool(inverse)), mode, float(sign), _stream())
+    _check(st, "vcnf_masked_affine_f32")
+    return out, logdet
+
+
+def affine_const(z, s, t, inverse):
+    dev = require_device(z, s, t)
+    z = z.contiguous()
+    b, c = z.shape[0], z.shape[1]
+    inner = int(z[0, 0].numel()) if z.dim() > 2 else 1
+    out = torch.empty_like(z)
+    with torch.cuda.device(dev):
+        st = lib().vcnf_affine_const_f32(_ptr(z), _ptr(s), _ptr(t), _ptr(out), b, c, inner,
+                                         int(bool(inverse)), _stream())
+    _check(st, "vcnf_affine_const_f32")
+    return out
+
+
+def permute(z, idx32):
+    dev = require_device(z)
+    z = z.contiguous()
+    b, c = z.shape[0], z.shape[1]
+    inner = int(z[0, 0].numel()) if z.dim() > 2 else 1
+    out = torch.empty_like(z)
+    with torch.cuda.device(dev):
+        st = lib().vcnf_permute_f32(_ptr(z), _ptr(idx32), _ptr(out), b, c, inner, _stream())
+    _check(st, "vcnf_permute_f32")
+    return out
+
+
+def diag_gaussian_log_prob(z, loc, log_scale, temperature=None, logp=None, sign=1.0):
+    dev = require_device(z, loc, log_scale, logp)
+    b = z.shape[0]
+    z2 = z.reshape(b, -1).contiguous()
+    mode = LD_ACCUM
+    if logp is None:
+        logp = torch.empty(b, dtype=torch.float32, device=dev)
+        mode = LD_STORE
+    lt = 0.0 if temperature is None else math.log(temperature)
+    with torch.cuda.device(dev):
+        st = lib().vcnf_diag_gaussian_log_prob_f32(_ptr(z2), _ptr(loc), _ptr(log_scale), lt, _ptr(logp),
+                                                   b, z2.shape[1], mode, float(sign), _stream())
+    _check(st, "vcnf_diag_gaussian_log_prob_f32")
+    return logp
+
+
+def diag_gaussian_sample(eps, loc, log_scale, temperature=None):
+    dev = require_device(eps, loc, log_scale)
+    b = eps.shape[0]
+    e2 = eps.reshape(b, -1).contiguous()
+    z = torch.empty_like(e2)
+    logp = torch.empty(b, dtype=torch.float32, device=dev)
+    lt = 0.0 if temperature is None else math.log(temperature)
+    with torch.cuda.device(dev):
+        st = lib().vcnf_diag_gaussian_sample_f32(_ptr(e2), _ptr(loc), _ptr(log_scale), lt, _ptr(z), _ptr(logp),
+                                                 b, e2.shape[1], _stream())
+    _check(st, "vcnf_diag_gaussian_sample_f32")
+    return z.view(eps.shape), logp

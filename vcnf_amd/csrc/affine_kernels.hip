@@ -1,0 +1,304 @@
+// Affine coupling, masked affine, per-channel affine, column gather and
+// diagonal-Gaussian end caps for MI355X (gfx950, wave64), with their C-ABI entry
+// points.  All of these are HBM-bound elementwise maps with a per-sample row
+// reduction: one group of G lanes (power of two <= 64) owns a sample, strides over
+// its row with coalesced accesses, and the log|det| partials are combined with
+// wave shuffles - no second pass over the data and no atomics.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/vcnf_hip.h"
+
+namespace vcnf {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float group_sum(float v, int G) {
+  for (int m = G >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__device__ __forceinline__ void put_ld(float* ld, long long b, float v, int mode) {
+  ld[b] = mode ? ld[b] + v : v;
+}
+
+// lanes per sample for a row of n elements
+static int pick_lanes(long long n) {
+  int G = 1;
+  while (G < 64 && G < n) G <<= 1;
+  return G;
+}
+
+static dim3 grid_for(long long batch, int G) {
+  const long long per_block = kBlock / G;
+  long long blocks = (batch + per_block - 1) / per_block;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  return dim3((unsigned)blocks);
+}
+
+// torch.sigmoid and log(sigmoid) evaluated like the reference does
+// (flows/affine/coupling.py:128-136): sigma = 1/(1+exp(-v)), then log(sigma).
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-v)); }
+
+// ------------------------------------------------------------------ affine coupling
+struct AffineArgs {
+  const float* z;
+  const float* param;
+  float* out;
+  float* logdet;
+  long long B;
+  int C, inner, t_off, d_t;
+  int scale_map, inverse, G, ld_mode;
+  float ld_sign;
+};
+
+__global__ __launch_bounds__(kBlock) void affine_coupling_kernel(const AffineArgs a) {
+  const int g = threadIdx.x & (a.G - 1);
+  const int per_block = kBlock / a.G;
+  const long long row = (long long)a.C * a.inner;          // elements of one sample
+  const long long t_lo = (long long)a.t_off * a.inner;     // transformed span inside a row
+  const long long t_n = (long long)a.d_t * a.inner;
+  const int npar = a.scale_map == VCNF_SCALE_NONE ? 1 : 2;
+  for (long long b = (long long)blockIdx.x * per_block + threadIdx.x / a.G; b < a.B;
+       b += (long long)gridDim.x * per_block) {
+    const float* zr = a.z + b * row;
+    float* orow = a.out + b * row;
+    const float* pr = a.param + b * (long long)npar * t_n;
+    float acc = 0.f;
+    for (long long e = g; e < row; e += a.G) {
+      float v = zr[e];
+      const long long te = e - t_lo;
+      if (te >= 0 && te < t_n) {
+        if (npar == 1) {                                   // coupling.py:139-141 / :165-167
+          const float p = pr[te];
+          v = a.inverse ? v - p : v + p;
+        } else {
+          const long long c = te / a.inner, i = te - c * a.inner;
+          const float shift = pr[(2 * c) * a.inner + i];   // param[:, 0::2]
+          const float sc = pr[(2 * c + 1) * a.inner + i];  // param[:, 1::2]
+          if (a.scale_map == VCNF_SCALE_EXP) {             // :124-126 / :150-152
+            if (a.inverse) { v = (v - shift) * expf(-sc); acc -= sc; }
+            else { v = v * expf(sc) + shift; acc += sc; }
+          } else {
+            const float sg = sigmoid_f(sc + 2.f);
+            const float lg = logf(sg);
+            const bool divide = (a.scale_map == VCNF_SCALE_SIGMOID) != (a.inverse != 0);
+            if (a.inverse) v = divide ? (v - shift) / sg : (v - shift) * sg;
+            else v = divide ? v / sg + shift : v * sg + shift;
+            acc += divide ? -lg : lg;
+          }
+        }
+      }
+      orow[e] = v;
+    }
+    acc = group_sum(acc, a.G);
+    if (g == 0 && a.logdet) put_ld(a.logdet, b, a.ld_sign * acc, a.ld_mode);
+  }
+}
+
+// ------------------------------------------------------------------ masked affine
+struct MaskedArgs {
+  const float *z, *s, *t, *b;
+  float* out;
+  float* logdet;
+  long long B;
+  int D, inverse, G, ld_mode;
+  float ld_sign;
+};
+
+__global__ __launch_bounds__(kBlock) void masked_affine_kernel(const MaskedArgs a) {
+  const int g = threadIdx.x & (a.G - 1);
+  const int per_block = kBlock / a.G;
+  const float nanv = __builtin_nanf("");
+  for (long long r = (long long)blockIdx.x * per_block + threadIdx.x / a.G; r < a.B;
+       r += (long long)gridDim.x * per_block) {
+    float acc = 0.f;
+    for (int j = g; j < a.D; j += a.G) {
+      const long long e = r * a.D + j;
+      const float m = a.b[j];
+      const float zv = a.z[e];
+      float sc = a.s ? a.s[e] : 0.f;
+      float tr = a.t ? a.t[e] : 0.f;
+      sc = isfinite(sc) ? sc : nanv;                       // coupling.py:205-208
+      tr = isfinite(tr) ? tr : nanv;
+      const float zm = m * zv;
+      const float om = 1.f - m;
+      float v;
+      if (a.inverse) v = zm + om * (zv - tr) * expf(-sc);  // :220
+      else v = zm + om * (zv * expf(sc) + tr);             // :209
+      a.out[e] = v;
+      acc += om * sc;                                      // :210 / :221
+    }
+    acc = group_sum(acc, a.G);
+    if (g == 0) put_ld(a.logdet, r, a.ld_sign * (a.inverse ? -acc : acc), a.ld_mode);
+  }
+}
+
+// ------------------------------------------------------------------ per-channel affine, gather
+struct ConstArgs {
+  const float *z, *s, *t;
+  float* out;
+  long long total;
+  int C, inner, inverse;
+};
+
+__global__ __launch_bounds__(kBlock) void affine_const_kernel(const ConstArgs a) {
+  for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < a.total; e += (long long)gridDim.x * kBlock) {
+    const int c = (int)((e / a.inner) % a.C);
+    const float s = a.s ? a.s[c] : 0.f, t = a.t ? a.t[c] : 0.f;
+    const float v = a.z[e];
+    a.out[e] = a.inverse ? (v - t) * expf(-s) : v * expf(s) + t;   // coupling.py:38 / :47
+  }
+}
+
+struct PermArgs {
+  const float* z;
+  const int32_t* idx;
+  float* out;
+  long long total;
+  int C, inner;
+};
+
+__global__ __launch_bounds__(kBlock) void permute_kernel(const PermArgs a) {
+  const long long row = (long long)a.C * a.inner;
+  for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < a.total; e += (long long)gridDim.x * kBlock) {
+    const long long b = e / row;
+    const long long r = e - b * row;
+    const int c = (int)(r / a.inner);
+    const int i = (int)(r - (long long)c * a.inner);
+    a.out[e] = a.z[b * row + (long long)a.idx[c] * a.inner + i];
+  }
+}
+
+// ------------------------------------------------------------------ diagonal Gaussian
+struct GaussArgs {
+  const float *in, *loc, *log_scale;
+  float* z;
+  float* logp;
+  long long B;
+  int D, G, ld_mode, sample;
+  float log_temp, ld_sign, norm;   // norm = -0.5 * D * log(2 pi)
+};
+
+__global__ __launch_bounds__(kBlock) void diag_gaussian_kernel(const GaussArgs a) {
+  const int g = threadIdx.x & (a.G - 1);
+  const int per_block = kBlock / a.G;
+  for (long long r = (long long)blockIdx.x * per_block + threadIdx.x / a.G; r < a.B;
+       r += (long long)gridDim.x * per_block) {
+    float acc = 0.f;
+    for (int j = g; j < a.D; j += a.G) {
+      const float ls = a.log_scale[j] + a.log_temp;
+      const float v = a.in[r * a.D + j];
+      if (a.sample) {                                      // base.py:639-641
+        a.z[r * a.D + j] = a.loc[j] + expf(ls) * v;
+        acc += ls + 0.5f * v * v;
+      } else {                                             // base.py:649-651
+        const float u = (v - a.loc[j]) / expf(ls);
+        acc += ls + 0.5f * u * u;
+      }
+    }
+    acc = group_sum(acc, a.G);
+    if (g == 0) put_ld(a.logp, r, a.ld_sign * (a.norm - acc), a.ld_mode);
+  }
+}
+
+static inline bool ok_ld(int m) { return m == VCNF_LD_STORE || m == VCNF_LD_ACCUM; }
+static inline int launched() { return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH; }
+
+}  // namespace vcnf
+
+using namespace vcnf;
+
+extern "C" int vcnf_abi_version(void) { return VCNF_ABI_VERSION; }
+
+extern "C" const char* vcnf_status_string(int status) {
+  switch (status) {
+    case VCNF_OK: return "ok";
+    case VCNF_ERR_NULL: return "required pointer is NULL";
+    case VCNF_ERR_SHAPE: return "inconsistent or unsupported sizes";
+    case VCNF_ERR_ALIGN: return "buffer not 4-byte aligned";
+    case VCNF_ERR_VALUE: return "minimal bin width/height too large for the number of bins";
+    case VCNF_ERR_UNSUPPORTED: return "unsupported mode";
+    case VCNF_ERR_LAUNCH: return "kernel launch failed";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int vcnf_affine_coupling_f32(const float* z, const float* param, float* out, float* logdet,
+                                        int64_t batch, int32_t channels, int32_t inner,
+                                        int32_t t_off, int32_t d_t, int scale_map, int inverse,
+                                        int ld_mode, float ld_sign, void* stream) {
+  if (batch < 0 || channels < 1 || inner < 1 || t_off < 0 || d_t < 0 || t_off + d_t > channels) return VCNF_ERR_SHAPE;
+  if (scale_map < VCNF_SCALE_EXP || scale_map > VCNF_SCALE_NONE) return VCNF_ERR_UNSUPPORTED;
+  if (!ok_ld(ld_mode)) return VCNF_ERR_UNSUPPORTED;
+  if (batch == 0) return VCNF_OK;
+  if (!z || !out || (d_t > 0 && !param)) return VCNF_ERR_NULL;
+  if (scale_map != VCNF_SCALE_NONE && !logdet) return VCNF_ERR_NULL;
+  AffineArgs a{z, param, out, logdet, batch, channels, inner, t_off, d_t, scale_map, inverse ? 1 : 0,
+               pick_lanes((long long)channels * inner), ld_mode, ld_sign};
+  hipLaunchKernelGGL(affine_coupling_kernel, grid_for(batch, a.G), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return launched();
+}
+
+extern "C" int vcnf_masked_affine_f32(const float* z, const float* s, const float* t, const float* b,
+                                      float* out, float* logdet, int64_t batch, int32_t features,
+                                      int inverse, int ld_mode, float ld_sign, void* stream) {
+  if (batch < 0 || features < 1) return VCNF_ERR_SHAPE;
+  if (!ok_ld(ld_mode)) return VCNF_ERR_UNSUPPORTED;
+  if (batch == 0) return VCNF_OK;
+  if (!z || !b || !out || !logdet) return VCNF_ERR_NULL;
+  MaskedArgs a{z, s, t, b, out, logdet, batch, features, inverse ? 1 : 0, pick_lanes(features), ld_mode, ld_sign};
+  hipLaunchKernelGGL(masked_affine_kernel, grid_for(batch, a.G), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return launched();
+}
+
+extern "C" int vcnf_affine_const_f32(const float* z, const float* s, const float* t, float* out,
+                                     int64_t batch, int32_t channels, int32_t inner, int inverse, void* stream) {
+  if (batch < 0 || channels < 1 || inner < 1) return VCNF_ERR_SHAPE;
+  if (batch == 0) return VCNF_OK;
+  if (!z || !out) return VCNF_ERR_NULL;
+  ConstArgs a{z, s, t, out, batch * (long long)channels * inner, channels, inner, inverse ? 1 : 0};
+  long long blocks = (a.total + kBlock - 1) / kBlock;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(affine_const_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return launched();
+}
+
+extern "C" int vcnf_permute_f32(const float* z, const int32_t* idx, float* out,
+                                int64_t batch, int32_t channels, int32_t inner, void* stream) {
+  if (batch < 0 || channels < 1 || inner < 1) return VCNF_ERR_SHAPE;
+  if (batch == 0) return VCNF_OK;
+  if (!z || !idx || !out) return VCNF_ERR_NULL;
+  PermArgs a{z, idx, out, batch * (long long)channels * inner, channels, inner};
+  long long blocks = (a.total + kBlock - 1) / kBlock;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(permute_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return launched();
+}
+
+static int gauss(const float* in, const float* loc, const float* log_scale, float log_temperature,
+                 float* z, float* logp, int64_t batch, int32_t features, int ld_mode, float ld_sign,
+                 int sample, void* stream) {
+  if (batch < 0 || features < 1) return VCNF_ERR_SHAPE;
+  if (!ok_ld(ld_mode)) return VCNF_ERR_UNSUPPORTED;
+  if (batch == 0) return VCNF_OK;
+  if (!in || !loc || !log_scale || !logp || (sample && !z)) return VCNF_ERR_NULL;
+  GaussArgs a{in, loc, log_scale, z, logp, batch, features, pick_lanes(features), ld_mode, sample,
+              log_temperature, ld_sign, (float)(-0.5 * (double)features * log(2.0 * M_PI))};
+  hipLaunchKernelGGL(diag_gaussian_kernel, grid_for(batch, a.G), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return launched();
+}
+
+extern "C" int vcnf_diag_gaussian_log_prob_f32(const float* z, const float* loc, const float* log_scale,
+                                               float log_temperature, float* logp, int64_t batch,
+                                               int32_t features, int ld_mode, float ld_sign, void* stream) {
+  return gauss(z, loc, log_scale, log_temperature, nullptr, logp, batch, features, ld_mode, ld_sign, 0, stream);
+}
+
+extern "C" int vcnf_diag_gaussian_sample_f32(const float* eps, const float* loc, const float* log_scale,
+                                             float log_temperature, float* z, float* logp, int64_t batch,
+                                             int32_t features, void* stream) {
+  return gauss(eps, loc, log_scale, log_temperature, z, logp, batch, features, VCNF_LD_STORE, 1.f, 1, stream);
+}

@@ -1,0 +1,207 @@
+"""Rational-quadratic-spline coupling on the HIP kernels of csrc/rqs_kernels.hip.
+
+Reference: normflow/flows/neural_spline/coupling.py - Coupling :18-137,
+PiecewiseCoupling :140-162, PiecewiseRationalQuadraticCDF :165-246,
+PiecewiseRationalQuadraticCoupling :249-343.  Direction names follow that file
+(nsf convention): ``forward`` is the density direction, ``inverse`` the
+sampling direction; the user-facing wrapper flips them.
+
+Per call, two kernels bracket the conditioner network:
+  1. vcnf_rqs_conditioner_input_f32 - gathers the identity features (through the
+     inverse unconditional spline when sampling) and appends the context;
+  2. vcnf_rqs_coupling_f32 - splines on both halves, scatter through the feature
+     index maps, per-sample log|det| reduction, optional accumulation into log_q.
+"""
+import warnings
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..base import Flow
+from ... import _lib
+from ...utils import splines
+
+
+class PiecewiseRationalQuadraticCDF(Flow):
+    """Unconditional per-feature spline; its logits are shared by the whole batch
+    and never leave L2/LDS inside the coupling kernel.  Stand-alone use goes
+    through the elementwise kernel with the logits broadcast by stride 0."""
+
+    def __init__(self, shape, num_bins=10, tails=None, tail_bound=1., identity_init=True,
+                 min_bin_width=splines.DEFAULT_MIN_BIN_WIDTH,
+                 min_bin_height=splines.DEFAULT_MIN_BIN_HEIGHT,
+                 min_derivative=splines.DEFAULT_MIN_DERIVATIVE):
+        super().__init__()
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.min_derivative = min_derivative
+        if torch.is_tensor(tail_bound):
+            raise NotImplementedError("tensor tail bounds are not built (SURVEY 8f row 4)")
+        self.tail_bound = tail_bound
+        self.tails = tails
+        self.num_bins = num_bins
+        if tails == 'linear':
+            n_deriv = num_bins - 1
+        elif tails == 'circular':
+            n_deriv = num_bins
+        else:
+            n_deriv = num_bins + 1
+        shape = list(shape)
+        if identity_init:                              # coupling.py:194-200
+            edge = float(np.log(np.exp(1 - min_derivative) - 1))
+            self.unnormalized_widths = nn.Parameter(torch.zeros(*shape, num_bins))
+            self.unnormalized_heights = nn.Parameter(torch.zeros(*shape, num_bins))
+            self.unnormalized_derivatives = nn.Parameter(torch.full((*shape, n_deriv), edge))
+        else:                                          # coupling.py:201-205
+            self.unnormalized_widths = nn.Parameter(torch.rand(*shape, num_bins))
+            self.unnormalized_heights = nn.Parameter(torch.rand(*shape, num_bins))
+            self.unnormalized_derivatives = nn.Parameter(torch.rand(*shape, n_deriv))
+
+    def logits(self):
+        return (self.unnormalized_widths, self.unnormalized_heights, self.unnormalized_derivatives)
+
+    def _spline(self, inputs, inverse):
+        n = inputs.shape[0]
+        uw, uh, ud = (p[None, ...].expand(n, *p.shape) for p in self.logits())
+        kw = dict(inverse=inverse, min_bin_width=self.min_bin_width,
+                  min_bin_height=self.min_bin_height, min_derivative=self.min_derivative)
+        if self.tails is None:
+            out, lad = splines.rational_quadratic_spline(inputs, uw, uh, ud, **kw)
+        else:
+            out, lad = splines.unconstrained_rational_quadratic_spline(
+                inputs, uw, uh, ud, tails=self.tails, tail_bound=self.tail_bound, **kw)
+        return out, torch.sum(lad, dim=list(range(1, lad.dim())))
+
+    def forward(self, inputs, context=None):
+        return self._spline(inputs, False)
+
+    def inverse(self, inputs, context=None):
+        return self._spline(inputs, True)
+
+
+class PiecewiseRationalQuadraticCoupling(Flow):
+    """``mask[i] > 0``: feature i is transformed by a spline whose logits come
+    from ``transform_net(identity_features[, context])``; other features pass
+    through (or through the unconditional spline)."""
+    takes_context = True
+
+    def __init__(self, mask, transform_net_create_fn, num_bins=10, tails=None, tail_bound=1.,
+                 apply_unconditional_transform=False, img_shape=None,
+                 min_bin_width=splines.DEFAULT_MIN_BIN_WIDTH,
+                 min_bin_height=splines.DEFAULT_MIN_BIN_HEIGHT,
+                 min_derivative=splines.DEFAULT_MIN_DERIVATIVE):
+        mask = torch.as_tensor(mask)
+        if mask.dim() != 1:
+            raise ValueError('Mask must be a 1-dim tensor.')
+        if mask.numel() <= 0:
+            raise ValueError('Mask can\'t be empty.')
+        if isinstance(tails, (list, tuple)) or torch.is_tensor(tail_bound):
+            raise NotImplementedError("per-feature tails / tensor tail bounds are not built (SURVEY 8f row 4)")
+        if tails == 'circular':
+            raise NotImplementedError("circular tails are not built (SURVEY 8f row 4)")
+        if tails not in (None, 'linear'):
+            raise RuntimeError('{} tails are not implemented.'.format(tails))
+        if img_shape:
+            raise NotImplementedError("image-shaped RQS coupling is a next row (SURVEY 8f row 3)")
+        super().__init__()
+        self.num_bins = num_bins
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.min_derivative = min_derivative
+        self.tails = tails
+        self.tail_bound = tail_bound
+        self.features = len(mask)
+        positions = torch.arange(self.features)
+        self.register_buffer('identity_features', positions.masked_select(mask <= 0))
+        self.register_buffer('transform_features', positions.masked_select(mask > 0))
+        if self.num_transform_features == 0:
+            raise ValueError('Mask selects no feature to transform.')
+        self.transform_net = transform_net_create_fn(
+            self.num_identity_features, self.num_transform_features * self._transform_dim_multiplier())
+        if apply_unconditional_transform:
+            self.unconditional_transform = PiecewiseRationalQuadraticCDF(
+                shape=[self.num_identity_features], num_bins=num_bins, tails=tails,
+                tail_bound=tail_bound, min_bin_width=min_bin_width,
+                min_bin_height=min_bin_height, min_derivative=min_derivative)
+        else:
+            self.unconditional_transform = None
+        self._i32 = {}
+
+    @property
+    def num_identity_features(self):
+        return len(self.identity_features)
+
+    @property
+    def num_transform_features(self):
+        return len(self.transform_features)
+
+    def _transform_dim_multiplier(self):
+        if self.tails == 'linear':
+            return self.num_bins * 3 - 1
+        return self.num_bins * 3 + 1
+
+    # ------------------------------------------------------------ helpers
+    def _index32(self, which):
+        src = self.identity_features if which == 'id' else self.transform_features
+        key = (which, src.device, src.data_ptr(), src._version)
+        hit = self._i32.get(key)
+        if hit is None:
+            if len(self._i32) > 8:
+                self._i32.clear()
+            hit = src.to(torch.int32).contiguous()
+            self._i32[key] = hit
+        return hit
+
+    def _logit_scale(self):
+        # coupling.py:314-321: width/height logits are divided by sqrt(hidden width)
+        for attr in ('hidden_features', 'hidden_channels'):
+            if hasattr(self.transform_net, attr):
+                return float(1.0 / np.sqrt(getattr(self.transform_net, attr)))
+        warnings.warn('Inputs to the softmax are not scaled down: initialization might be bad.')
+        return 1.0
+
+    def _cfg(self, scaled):
+        return _lib.make_cfg(self.num_bins, self.tails, tail_bound=self.tail_bound,
+                             min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                             min_derivative=self.min_derivative,
+                             wh_scale=self._logit_scale() if scaled else 1.0)
+
+    def _check(self, inputs):
+        if inputs.dim() not in [2, 4]:
+            raise ValueError('Inputs must be a 2D or a 4D tensor.')
+        if inputs.shape[1] != self.features:
+            raise ValueError('Expected features = {}, got {}.'.format(self.features, inputs.shape[1]))
+        if inputs.dim() == 4:
+            raise NotImplementedError("image-shaped RQS coupling is a next row (SURVEY 8f row 3)")
+
+    def _params(self, inputs, context, sampling):
+        """Conditioner call.  Sampling direction: the identity half first goes
+        through the inverse unconditional spline (coupling.py:110-114)."""
+        shared = self.unconditional_transform.logits() if self.unconditional_transform is not None else None
+        net = self.transform_net
+        fused_concat = context is not None and hasattr(net, 'trunk') and getattr(net, 'preprocessing', None) is None
+        first = _lib.rqs_conditioner_input(inputs, self._index32('id'), context if fused_concat else None,
+                                           shared, self._cfg(False), sampling and shared is not None)
+        if fused_concat:
+            return net.trunk(first, context)
+        return net(first, context) if context is not None else net(first)
+
+    def _run(self, inputs, context, sampling, log_q=None, sign=1.0):
+        self._check(inputs)
+        params = self._params(inputs, context, sampling)
+        expect = self.num_transform_features * self._transform_dim_multiplier()
+        if params.dim() != 2 or params.shape[1] != expect:
+            raise ValueError('transform_net returned %s, expected [B, %d]' % (tuple(params.shape), expect))
+        shared = self.unconditional_transform.logits() if self.unconditional_transform is not None else None
+        return _lib.rqs_coupling(inputs, params, self._index32('tf'), self._index32('id'), shared,
+                                 self._cfg(True), sampling, logdet=log_q, sign=sign)
+
+    # ------------------------------------------------------------ nsf-convention API
+    def forward(self, inputs, context=None):
+        """Density direction (coupling.py:70-96)."""
+        return self._run(inputs, context, False)
+
+    def inverse(self, inputs, context=None):
+        """Sampling direction (coupling.py:98-125)."""
+        return self._run(inputs, context, True)

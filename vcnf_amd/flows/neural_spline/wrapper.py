@@ -1,0 +1,53 @@
+"""User-facing neural-spline coupling layer.
+Reference: normflow/flows/neural_spline/wrapper.py:15-75."""
+from torch import nn
+
+from ..base import Flow
+from .coupling import PiecewiseRationalQuadraticCoupling
+from ...nets.resnet import ResidualNet
+from ...utils.masks import create_alternating_binary_mask
+
+
+class CoupledRationalQuadraticSpline(Flow):
+    """RQS coupling with a ResidualNet conditioner on an alternating mask
+    (odd features transformed unless ``reverse_mask``), linear tails and the
+    unconditional spline on the identity half.  normflow convention:
+    ``forward`` samples, ``inverse`` evaluates density (wrapper.py:69-75).
+
+    Extension over the reference signature: ``num_context_channels`` builds the
+    conditional variant of config C3 (ResidualNet with context_features); the
+    reference reaches the same module by constructing
+    PiecewiseRationalQuadraticCoupling directly.  State-dict keys are identical."""
+    takes_context = True
+
+    def __init__(self, num_input_channels, num_blocks, num_hidden_channels, num_bins=8,
+                 tails='linear', tail_bound=3., activation=nn.ReLU, dropout_probability=0.,
+                 reverse_mask=False, num_context_channels=None):
+        super().__init__()
+
+        def make_net(in_features, out_features):
+            return ResidualNet(in_features=in_features, out_features=out_features,
+                               context_features=num_context_channels,
+                               hidden_features=num_hidden_channels, num_blocks=num_blocks,
+                               activation=activation(), dropout_probability=dropout_probability,
+                               use_batch_norm=False)
+
+        self.prqct = PiecewiseRationalQuadraticCoupling(
+            mask=create_alternating_binary_mask(num_input_channels, even=reverse_mask),
+            transform_net_create_fn=make_net, num_bins=num_bins, tails=tails, tail_bound=tail_bound,
+            apply_unconditional_transform=True)
+
+    def forward(self, z, context=None):
+        z, log_det = self.prqct.inverse(z, context)
+        return z, log_det.view(-1)
+
+    def inverse(self, z, context=None):
+        z, log_det = self.prqct(z, context)
+        return z, log_det.view(-1)
+
+    # accumulate-into-log_q forms used by NormalizingFlow (core.py:153-155 / :179-181)
+    def forward_into(self, z, log_q, context=None):
+        return self.prqct._run(z, context, True, log_q, -1.0)[0]
+
+    def inverse_into(self, z, log_q, context=None):
+        return self.prqct._run(z, context, False, log_q, 1.0)[0]

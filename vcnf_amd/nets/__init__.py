@@ -1,0 +1,2 @@
+from .mlp import MLP                                   # noqa: F401
+from .resnet import ResidualBlock, ResidualNet         # noqa: F401

@@ -1,0 +1,77 @@
+"""Residual conditioner of the RQS couplings (callee of the hot path).
+
+Same parameter names as the reference (``initial_layer``, ``blocks.{i}.
+linear_layers.{0,1}``, ``blocks.{i}.context_layer``, ``final_layer``) so its
+checkpoints load unchanged.  Reference: normflow/nets/resnet.py:8-106.
+The dense layers are plain GEMMs on PyTorch-ROCm (MFMA through hipBLASLt).
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+
+class ResidualBlock(nn.Module):
+    """x + Linear(drop(act(Linear(act(x))))), optionally GLU-gated by a context
+    projection (resnet.py:38-57)."""
+
+    def __init__(self, features, context_features, activation=F.relu,
+                 dropout_probability=0., use_batch_norm=False, zero_initialization=True):
+        super().__init__()
+        self.activation = activation
+        self.use_batch_norm = use_batch_norm
+        if use_batch_norm:
+            self.batch_norm_layers = nn.ModuleList(
+                [nn.BatchNorm1d(features, eps=1e-3) for _ in range(2)])
+        if context_features is not None:
+            self.context_layer = nn.Linear(context_features, features)
+        self.linear_layers = nn.ModuleList([nn.Linear(features, features) for _ in range(2)])
+        self.dropout = nn.Dropout(p=dropout_probability)
+        if zero_initialization:                       # resnet.py:34-36
+            for p in (self.linear_layers[1].weight, self.linear_layers[1].bias):
+                nn.init.uniform_(p, -1e-3, 1e-3)
+
+    def forward(self, inputs, context=None):
+        h = inputs
+        for i in range(2):
+            if self.use_batch_norm:
+                h = self.batch_norm_layers[i](h)
+            h = self.activation(h)
+            if i == 1:
+                h = self.dropout(h)
+            h = self.linear_layers[i](h)
+        if context is not None:
+            h = F.glu(torch.cat((h, self.context_layer(context)), dim=1), dim=1)
+        return inputs + h
+
+
+class ResidualNet(nn.Module):
+    """Linear -> num_blocks x ResidualBlock -> Linear on flat feature vectors."""
+
+    def __init__(self, in_features, out_features, hidden_features, context_features=None,
+                 num_blocks=2, activation=F.relu, dropout_probability=0.,
+                 use_batch_norm=False, preprocessing=None):
+        super().__init__()
+        self.hidden_features = hidden_features      # read by the coupling for the 1/sqrt(H) logit scale
+        self.context_features = context_features
+        self.preprocessing = preprocessing
+        first_in = in_features + (context_features or 0)
+        self.initial_layer = nn.Linear(first_in, hidden_features)
+        self.blocks = nn.ModuleList([
+            ResidualBlock(hidden_features, context_features, activation=activation,
+                          dropout_probability=dropout_probability, use_batch_norm=use_batch_norm)
+            for _ in range(num_blocks)])
+        self.final_layer = nn.Linear(hidden_features, out_features)
+
+    def forward(self, inputs, context=None):
+        h = inputs if self.preprocessing is None else self.preprocessing(inputs)
+        if context is not None:
+            h = torch.cat((h, context), dim=1)
+        return self.trunk(h, context)
+
+    def trunk(self, first_in, context=None):
+        """Everything after the (identity | context) concatenation; the RQS
+        coupling calls this directly with the buffer its gather kernel wrote."""
+        h = self.initial_layer(first_in)
+        for block in self.blocks:
+            h = block(h, context=context)
+        return self.final_layer(h)
