@@ -77,13 +77,14 @@ def assert_close(got, want, rtol, atol, what=""):
         what, int(bad.sum()), g.numel(), float(err.max()), float(tol[err.argmax()]))
 
 
-def within_reference_noise(got, ref32, ref64, slack=2.0, max_slack=4.0, floor=1e-6, what=""):
+def within_reference_noise(got, ref32, ref64, slack=2.0, max_slack=8.0, floor=1e-6, what=""):
     """the build must be no worse than the reference's own fp32
     error.  |got - ref64| <= slack*|ref32 - ref64| elementwise is too strict (a
     different rounding order moves single ill-conditioned elements), so the bound
     is applied to the error distribution relative to the fp64 result: the build's
-    mean error may not exceed slack x the reference's mean fp32 error, and its
-    worst element max_slack x the reference's worst element (plus floor)."""
+    mean and 99.9th-percentile error may not exceed slack x the reference's own,
+    and its single worst element max_slack x the reference's worst (plus floor;
+    errors are relative to 1 + |ref64|)."""
     got = got.detach().cpu().double()
     r32, r64 = torch.as_tensor(ref32).double(), torch.as_tensor(ref64).double()
     ok = torch.isfinite(r64) & torch.isfinite(got)
@@ -92,11 +93,13 @@ def within_reference_noise(got, ref32, ref64, slack=2.0, max_slack=4.0, floor=1e
     scale = 1.0 + r64[ok].abs()
     e_build = ((got[ok] - r64[ok]).abs() / scale)
     e_ref = ((r32[ok] - r64[ok]).abs() / scale)
-    assert e_build.max() <= max_slack * e_ref.max() + floor, "%s max err %.3e vs ref fp32 %.3e" % (
-        what, float(e_build.max()), float(e_ref.max()))
-    assert e_build.mean() <= slack * e_ref.mean() + floor, "%s mean err %.3e vs ref fp32 %.3e" % (
-        what, float(e_build.mean()), float(e_ref.mean()))
-
+    q = torch.tensor([0.999], dtype=torch.float64)
+    stats = (("mean", e_build.mean(), e_ref.mean(), slack),
+             ("p99.9", torch.quantile(e_build, q)[0], torch.quantile(e_ref, q)[0], slack),
+             ("max", e_build.max(), e_ref.max(), max_slack))
+    for name, eb, er, k in stats:
+        assert eb <= k * er + floor, "%s %s err %.3e vs ref fp32 %.3e (allowed x%g)" % (
+            what, name, float(eb), float(er), k)
 
 def parity(got, ref32, ref64, rtol=2e-5, atol=2e-5, what="", noise_floor=0.0):
     """Parity of an fp32 result with the reference's fp32 output, aware of the

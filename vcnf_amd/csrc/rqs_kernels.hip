@@ -15,6 +15,7 @@
 // 4D (x) + 4 d_t P (params) + 4D (y) + 4..8 (logdet).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/vcnf_hip.h"
 #include "rqs_math.hpp"
@@ -42,6 +43,7 @@ struct CouplingArgs {
   int JC;         // transformed features per params chunk (== d_t: whole rows)
   int vec_x;      // x / y tiles may use 16-byte accesses
   int vec_p;      // params chunks may use 16-byte accesses
+  int dbg;        // scratch experiments only (VCNF_DBG env): 1 = skip the spline arithmetic
   int sh_mode;    // shared (unconditional) spline: 0 absent, 1 knot tables in LDS, 2 logits read from HBM/L2
   int ld_mode;
   float ld_sign;
@@ -176,6 +178,127 @@ __global__ __launch_bounds__(kBlock) void rqs_coupling_kernel(const CouplingArgs
   if (INV && a.bad && bad) atomicAdd(a.bad, 1);
 }
 
+// Fast path of the same kernel for tiles that are one contiguous, 16-byte aligned
+// block of HBM (whole params rows per tile): the NEXT tile's x and params rows are
+// requested into registers before the current tile is evaluated and written to LDS
+// after the barrier that retires the current tile, so every workgroup keeps one
+// tile (~25 KB for config C3) in flight while it computes.
+template <int KT, bool INV, int NPF>
+__global__ __launch_bounds__(kBlock) void rqs_coupling_pf_kernel(const CouplingArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x;
+  const RqsConst& c = a.c;
+  const int K = KT > 0 ? KT : c.K;
+  const int tabw = 3 * (K + 1);
+  const int n_x = a.S * a.D;
+  const int n_p = ((a.S * a.d_t * a.P + 3) >> 2) << 2;
+  float* xt = smem;
+  float* yt = xt + n_x;
+  float* pt = yt + n_x;
+  float* tab = pt + n_p;
+  int* tfi = reinterpret_cast<int*>(tab + (((a.sh_mode == 1 ? a.d_id * tabw : 0) + 3) >> 2 << 2));
+  int* idi = tfi + a.d_t;
+
+  for (int i = tid; i < a.d_t; i += kBlock) tfi[i] = a.tf_idx[i];
+  for (int i = tid; i < a.d_id; i += kBlock) idi[i] = a.id_idx[i];
+  if (a.sh_mode == 1) {
+    RqsConst cs = c;
+    cs.K = K;
+    for (int f = tid; f < a.d_id; f += kBlock) {
+      SplitLogits p{a.sh_w + (long long)f * K, a.sh_h + (long long)f * K, a.sh_d + (long long)f * a.Pd,
+                    K, 1.f, c.edge_logit, c.tails};
+      rqs_build_table(p, cs, tab + f * tabw);
+    }
+  }
+
+  const int g = tid & (a.G - 1);
+  const int s = tid / a.G;
+  const int rowlen4 = (a.d_t * a.P) >> 2;     // float4 per params row (host guarantees divisibility)
+  const int d4 = a.D >> 2;
+  const long long ntiles = (a.B + a.S - 1) / a.S;
+  bool bad = false;
+
+  float4 rp[NPF];
+  float4 rx[2];
+#define VCNF_REQUEST(TILE)                                                                  \
+  {                                                                                         \
+    const long long rb0 = (TILE) * a.S;                                                     \
+    const int rrows = (int)min((long long)a.S, a.B - rb0);                                  \
+    const float4* sp = reinterpret_cast<const float4*>(a.params) + rb0 * rowlen4;           \
+    const float4* sx = reinterpret_cast<const float4*>(a.x) + rb0 * d4;                     \
+    const int rnp4 = rrows * rowlen4, rnx4 = rrows * d4;                                    \
+    _Pragma("unroll") for (int i = 0; i < NPF; ++i) {                                       \
+      const int idx = tid + i * kBlock;                                                     \
+      rp[i] = idx < rnp4 ? sp[idx] : make_float4(0.f, 0.f, 0.f, 0.f);                       \
+    }                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                         \
+      const int idx = tid + i * kBlock;                                                     \
+      rx[i] = idx < rnx4 ? sx[idx] : make_float4(0.f, 0.f, 0.f, 0.f);                       \
+    }                                                                                       \
+  }
+
+  long long tile = blockIdx.x;
+  if (tile < ntiles) VCNF_REQUEST(tile)
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long long b0 = tile * a.S;
+    const int rows = (int)min((long long)a.S, a.B - b0);
+    const int np4 = rows * rowlen4, nx4 = rows * d4;
+    __syncthreads();   // LDS tiles of the previous round fully consumed (and tables built)
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int idx = tid + i * kBlock;
+      if (idx < np4) reinterpret_cast<float4*>(pt)[idx] = rp[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * kBlock;
+      if (idx < nx4) reinterpret_cast<float4*>(xt)[idx] = rx[i];
+    }
+    if (tile + gridDim.x < ntiles) VCNF_REQUEST(tile + gridDim.x)   // stays in flight during the evaluation
+    __syncthreads();
+
+    float acc = 0.f;
+    if (s < rows) {
+      const int seg = a.d_t * a.P;
+      for (int j = g; j < a.d_t; j += a.G) {
+        const int col = tfi[j];
+        const float xv = xt[s * a.D + col];
+        PackedLogits p{pt + s * seg + j * a.P, K, c.wh_scale, c.edge_logit, c.tails};
+        float yv, lad;
+        if (a.dbg == 1) { yv = xv + p.q[0] * 0.f; lad = p.q[22]; }
+        else rqs_point<KT, INV>(xv, p, c, yv, lad, bad);
+        yt[s * a.D + col] = yv;
+        acc += lad;
+      }
+      for (int j = g; j < a.d_id; j += a.G) {
+        const int col = idi[j];
+        const float xv = xt[s * a.D + col];
+        float yv = xv, lad = 0.f;
+        if (a.dbg == 1) {
+        } else if (a.sh_mode == 1) {
+          rqs_point_table<INV>(xv, tab + j * tabw, c, yv, lad, bad);
+        } else if (a.sh_mode == 2) {
+          SplitLogits p{a.sh_w + (long long)j * K, a.sh_h + (long long)j * K, a.sh_d + (long long)j * a.Pd,
+                        K, 1.f, c.edge_logit, c.tails};
+          rqs_point<KT, INV>(xv, p, c, yv, lad, bad);
+        }
+        yt[s * a.D + col] = yv;
+        acc += lad;
+      }
+    }
+    for (int m = a.G >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (g == 0 && s < rows) {
+      const float v = a.ld_sign * acc;
+      a.logdet[b0 + s] = a.ld_mode ? a.logdet[b0 + s] + v : v;
+    }
+    __syncthreads();
+    float4* dst = reinterpret_cast<float4*>(a.y) + b0 * d4;
+    for (int i = tid; i < nx4; i += kBlock) dst[i] = reinterpret_cast<const float4*>(yt)[i];
+  }
+#undef VCNF_REQUEST
+  if (INV && a.bad && bad) atomicAdd(a.bad, 1);
+}
+
 // ------------------------------------------------------------------ elementwise
 struct ElemArgs {
   const float *x, *uw, *uh, *ud;
@@ -300,6 +423,17 @@ static void launch_coupling(const CouplingArgs& a, int K, dim3 grid, size_t lds,
 }
 
 template <bool INV>
+static void launch_coupling_pf(const CouplingArgs& a, int K, dim3 grid, size_t lds, hipStream_t st) {
+  switch (K) {
+    case 4: hipLaunchKernelGGL((rqs_coupling_pf_kernel<4, INV, 8>), grid, dim3(kBlock), lds, st, a); break;
+    case 8: hipLaunchKernelGGL((rqs_coupling_pf_kernel<8, INV, 8>), grid, dim3(kBlock), lds, st, a); break;
+    case 10: hipLaunchKernelGGL((rqs_coupling_pf_kernel<10, INV, 8>), grid, dim3(kBlock), lds, st, a); break;
+    case 16: hipLaunchKernelGGL((rqs_coupling_pf_kernel<16, INV, 8>), grid, dim3(kBlock), lds, st, a); break;
+    default: hipLaunchKernelGGL((rqs_coupling_pf_kernel<0, INV, 8>), grid, dim3(kBlock), lds, st, a); break;
+  }
+}
+
+template <bool INV>
 static void launch_elem(const ElemArgs& a, int K, dim3 grid, hipStream_t st) {
   switch (K) {
     case 4: hipLaunchKernelGGL((rqs_elementwise_kernel<4, INV>), grid, dim3(kBlock), 0, st, a); break;
@@ -380,6 +514,7 @@ extern "C" int vcnf_rqs_coupling_f32(const float* x, const float* params,
   a.G = pick_group(d_t, d_id, a.P, K, a.sh_mode);
   a.S = kBlock / a.G;
   a.ld_mode = ld_mode; a.ld_sign = ld_sign;
+  { const char* e = getenv("VCNF_DBG"); a.dbg = e ? atoi(e) : 0; }
 
   // LDS plan: x tile + y tile + tables + indices are fixed; the params chunk takes the rest.
   const size_t fixed = fixed_lds(a.S, D, d_id, K, a.sh_mode);
@@ -407,8 +542,17 @@ extern "C" int vcnf_rqs_coupling_f32(const float* x, const float* params,
   const long long max_grid = 256 * 8;
   dim3 grid((unsigned)(ntiles < max_grid ? ntiles : max_grid));
   hipStream_t st = (hipStream_t)stream;
-  if (inverse) launch_coupling<true>(a, K, grid, lds, st);
-  else launch_coupling<false>(a, K, grid, lds, st);
+  // prefetching fast path: whole rows per tile, everything 16-byte sized and aligned, tile within
+  // the 8 + 2 float4 register slots a thread keeps in flight
+  const bool pf = a.JC == d_t && a.vec_x && a.vec_p && (rowlen & 3) == 0 && (D & 3) == 0 &&
+                  (long long)a.S * rowlen <= 8LL * 4 * kBlock && (long long)a.S * D <= 2LL * 4 * kBlock;
+  if (pf) {
+    if (inverse) launch_coupling_pf<true>(a, K, grid, lds, st);
+    else launch_coupling_pf<false>(a, K, grid, lds, st);
+  } else {
+    if (inverse) launch_coupling<true>(a, K, grid, lds, st);
+    else launch_coupling<false>(a, K, grid, lds, st);
+  }
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }
 
