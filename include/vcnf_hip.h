@@ -107,6 +107,33 @@ int vcnf_rqs_conditioner_input_f32(const float* x, int64_t batch, int32_t featur
                                    const vcnf_rqs_cfg* cfg, int apply_inverse_shared,
                                    float* out, void* stream);
 
+/* Packed conditioner weights of one fused RQS coupling layer: ONE device buffer of
+ * vcnf_rqs_layer_fused_pack_floats(ctx_dim) floats holding the ResidualNet's nn.Linear
+ * weights (nets/resnet.py:78-90) re-ordered into matrix-core fragments, in the order
+ *   W0 | b0 | per block: WA | ba | WB | bb | (WC | bc if ctx_dim > 0) | WF | bf
+ * (exact fragment order: vcnf_amd/fused.py::pack_layer, csrc/fused_layer.hip PackLayout). */
+int64_t vcnf_rqs_layer_fused_pack_floats(int32_t ctx_dim);
+
+/* 1 if vcnf_rqs_layer_fused_f32 has a kernel for this layer shape, else 0. */
+int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t ctx_dim, int32_t hidden,
+                                   int32_t num_blocks, int32_t num_bins, int32_t tails);
+
+/* One RQS coupling layer INCLUDING its ResidualNet conditioner in a single kernel:
+ * Coupling.forward / .inverse (flows/neural_spline/coupling.py:70-96 / :98-125) with
+ * transform_net = ResidualNet(ReLU, no batch norm, dropout 0; nets/resnet.py:92-106)
+ * evaluated on the fp32 matrix cores.  Same results contract as
+ * vcnf_rqs_conditioner_input_f32 + the dense layers + vcnf_rqs_coupling_f32; the
+ * conditioner output never touches HBM.  context[B, ctx_dim] may be NULL when
+ * ctx_dim = 0.  x, y, context must be 16-byte aligned. */
+int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, float* logdet,
+                             int64_t batch, const int32_t* transform_idx, int32_t d_t,
+                             const int32_t* identity_idx, int32_t d_id, int32_t ctx_dim,
+                             int32_t hidden, int32_t num_blocks,
+                             const float* wpack, int64_t wpack_floats,
+                             const float* shared_w, const float* shared_h, const float* shared_d,
+                             const vcnf_rqs_cfg* cfg, int inverse,
+                             int ld_mode, float ld_sign, int32_t* bad_disc, void* stream);
+
 /* Affine coupling on z[B, C, inner] (inner = H*W, 1 for 2-D inputs).
  * Replaces AffineCoupling.forward / .inverse (flows/affine/coupling.py:113-142 /
  * :144-168) together with the channel Split / Merge around it

@@ -32,9 +32,21 @@ def dev(t):
     return t.cuda()
 
 
-def load(module, sd):
+def load(module, sd, fused=True):
     module.load_state_dict(sd, strict=True)
-    return module.cuda().eval()
+    return set_fused(module.cuda().eval(), fused)
+
+
+def set_fused(module, flag):
+    """Route eligible RQS couplings through the single-kernel layer (True) or through
+    the gather kernel + torch GEMMs + spline kernel (False)."""
+    for m in module.modules():
+        if isinstance(m, nf.flows.PiecewiseRationalQuadraticCoupling):
+            m.fused = flag
+    return module
+
+
+FUSED = pytest.mark.parametrize("fused", [True, False], ids=["fused", "split"])
 
 
 # ---------------------------------------------------------------- splines (G1, G2)
@@ -126,11 +138,12 @@ def test_spline_generic_bin_counts_vs_oracle(hip):
 
 
 # ---------------------------------------------------------------- RQS coupling layers (G3, G4)
+@FUSED
 @pytest.mark.parametrize("rm", [0, 1])
-def test_g3_coupled_rqs_layer(hip, rm):
+def test_g3_coupled_rqs_layer(hip, rm, fused):
     fx = fixture("g3_crqs_layer")
     sd, _ = state_for(fx, "rm%d" % rm, 301 + rm, final_gain=2.0)
-    m = load(nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8, reverse_mask=bool(rm)), sd)
+    m = load(nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8, reverse_mask=bool(rm)), sd, fused)
     x = dev(T(fx["x"]))
     pre = "rm%d/" % rm
     with torch.no_grad():
@@ -144,7 +157,7 @@ def test_g3_coupled_rqs_layer(hip, rm):
     nf.check_discriminant()
 
 
-def _cond_layer(tag, fx):
+def _cond_layer(tag, fx, fused=True):
     d, c, h, nb, k, tb, kind = fx[tag + "/cfg"]
     d, c, h, nb, k = int(d), int(c), int(h), int(nb), int(k)
     mask = (nf.utils.create_alternating_binary_mask(d, even=False) if kind == 0
@@ -153,13 +166,14 @@ def _cond_layer(tag, fx):
     m = nf.flows.PiecewiseRationalQuadraticCoupling(mask, net, num_bins=k, tails="linear", tail_bound=float(tb),
                                                     apply_unconditional_transform=True)
     sd, _ = state_for(fx, tag, 401 + d, final_gain=2.0)
-    return load(m, sd), d
+    return load(m, sd, fused), d
 
 
+@FUSED
 @pytest.mark.parametrize("tag", ["d64", "d21", "d7k4"])
-def test_g4_conditional_coupling(hip, tag):
+def test_g4_conditional_coupling(hip, tag, fused):
     fx = fixture("g4_cond_prqc")
-    m, d = _cond_layer(tag, fx)
+    m, d = _cond_layer(tag, fx, fused)
     x, ctx = dev(T(fx[tag + "/x"])), dev(T(fx[tag + "/ctx"]))
     with torch.no_grad():
         z, ld = m.forward(x, ctx)
@@ -205,7 +219,7 @@ def test_conditioner_input_matches_kernel_output(hip):
     """Sampling direction: the identity values handed to the conditioner and the
     ones written to the output come from two kernels and must agree bitwise."""
     fx = fixture("g4_cond_prqc")
-    m, d = _cond_layer("d64", fx)
+    m, d = _cond_layer("d64", fx, fused=False)
     x, ctx = dev(T(fx["d64/x"])), dev(T(fx["d64/ctx"]))
     with torch.no_grad():
         first = _lib.rqs_conditioner_input(x, m._index32('id'), ctx, m.unconditional_transform.logits(),
@@ -222,11 +236,12 @@ def _c3_model(layers=12, d=64, c=16, hidden=128, blocks=2, k=8):
     return nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows)
 
 
-def test_g5_c3_stack_log_prob_and_sample(hip):
+@FUSED
+def test_g5_c3_stack_log_prob_and_sample(hip, fused):
     """North-star parity: config C3's stack on the well-conditioned fixture."""
     fx = fixture("g5_c3_stack")
     sd, _ = state_for(fx, "c3", 501, final_gain=1.0)
-    model = load(_c3_model(), sd)
+    model = load(_c3_model(), sd, fused)
     x, ctx, eps = (dev(T(fx[n])) for n in ("x", "ctx", "eps"))
     with torch.no_grad():
         lp = model.log_prob(x, ctx)
@@ -251,14 +266,15 @@ def test_g5_c3_stack_log_prob_and_sample(hip):
     nf.check_discriminant()
 
 
-def test_g5_c3_stack_stress_weights(hip):
+@FUSED
+def test_g5_c3_stack_stress_weights(hip, fused):
     """Same stack with wild conditioner logits (derivatives at the 1e-3 floor): the
     reference's own fp32 log_prob is up to 0.3 away from fp64 here; the build must
     stay inside that noise envelope."""
     fx = fixture("g5_c3_stack")
     sd, _ = state_for(fx, "c3_stress", 501, final_gain=6.0)
     sd.update({k[len("c3/int/"):]: T(v) for k, v in fx.items() if k.startswith("c3/int/")})
-    model = load(_c3_model(), sd)
+    model = load(_c3_model(), sd, fused)
     x, ctx, eps = (dev(T(fx[n])) for n in ("x", "ctx", "eps"))
     with torch.no_grad():
         parity(model.log_prob(x, ctx), fx["c3_stress/lp32"], fx["c3_stress/lp64"], what="log_prob")
@@ -404,7 +420,8 @@ def _check_vs_oracle(m, o32, o64, x, ctx, what, noise=None):
     return seen
 
 
-def test_c3_layer_vs_oracle_ragged_batches(hip):
+@FUSED
+def test_c3_layer_vs_oracle_ragged_batches(hip, fused):
     """Batch sizes around the tile size (8 samples per workgroup pass), 1 row, and
     a large odd size; the oracle's fp32 noise measured at B=4099 is the floor for
     the tiny batches."""
@@ -412,10 +429,10 @@ def test_c3_layer_vs_oracle_ragged_batches(hip):
     sd, _ = state_for(fx, "c3", 501, final_gain=2.0)
     sub = {k: v for k, v in sd.items() if k.startswith("flows.0.")}
     m = load(nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8, num_context_channels=16),
-             {k[len("flows.0."):]: v for k, v in sub.items()})
+             {k[len("flows.0."):]: v for k, v in sub.items()}, fused)
     o32, o64 = _oracle_pair(sub, "flows.0.prqct.", 8, 3.0, 128)
     noise = None
-    for batch in (4099, 257, 9, 8, 7, 3, 1):
+    for batch in (4099, 257, 129, 128, 127, 9, 8, 7, 3, 1):
         g = torch.Generator().manual_seed(batch)
         x, ctx = 1.2 * torch.randn(batch, 64, generator=g), torch.randn(batch, 16, generator=g)
         seen = _check_vs_oracle(m, o32, o64, x, ctx, "B=%d" % batch, noise)
@@ -517,12 +534,13 @@ def test_requires_grad_is_refused(hip):
 
 
 # ---------------------------------------------------------------- full-size properties (BASELINE configs)
-def test_c3_full_size_round_trip(hip):
+@FUSED
+def test_c3_full_size_round_trip(hip, fused):
     """Config C3 at the benchmark batch (1M x 64, 12 layers, context 16): sample
     then log_prob must reproduce log_q and the base noise (size-independent
     properties; the oracle cannot run this size in seconds)."""
     torch.manual_seed(0)
-    model = _c3_model().cuda().eval()
+    model = set_fused(_c3_model().cuda().eval(), fused)
     with torch.no_grad():
         for n, p in model.named_parameters():
             if "unnormalized" in n:
@@ -564,3 +582,40 @@ def test_c2_full_size_round_trip(hip):
         lp = model.log_prob(z)
         err = (lp - lq).abs() / (1.0 + lq.abs())
         assert float(err.max()) < 1e-5, float(err.max())
+
+
+def test_fused_path_is_taken_and_matches_split_path(hip):
+    """The single-kernel layer and the three-step path are two implementations of the
+    same layer: same outputs to fp32 rounding, and the fused one really is selected
+    for the C3 layer shape (with and without context)."""
+    from vcnf_amd import fused as fz
+    torch.manual_seed(21)
+    for ctx_dim in (16, None):
+        m = nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8, num_context_channels=ctx_dim).cuda().eval()
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if "unnormalized" in n:
+                    p.normal_(0, 0.5)
+                elif "final_layer.weight" in n:
+                    p.normal_(0, 1.0 / np.sqrt(128))
+        x = torch.randn(1000, 64, device="cuda")
+        ctx = torch.randn(1000, 16, device="cuda") if ctx_dim else None
+        assert fz.eligible(m.prqct, ctx)
+        with torch.no_grad():
+            for dirn in ("inverse", "forward"):
+                m.prqct.fused = True
+                zf, lf = getattr(m, dirn)(x, context=ctx)
+                m.prqct.fused = False
+                zs, ls = getattr(m, dirn)(x, context=ctx)
+                assert_close(zf, zs.cpu(), rtol=1e-4, atol=1e-4, what="%s z" % dirn)
+                assert_close(lf, ls.cpu(), rtol=1e-4, atol=2e-3, what="%s ld" % dirn)
+        # weights changed in place -> the packed copy is rebuilt
+        m.prqct.fused = True
+        with torch.no_grad():
+            z0, _ = m.inverse(x, context=ctx)
+            m.prqct.transform_net.final_layer.bias.add_(0.3)
+            z1, _ = m.inverse(x, context=ctx)
+        assert not torch.equal(z0, z1)
+    # shapes outside the kernel's family fall back to the split path
+    other = nf.flows.CoupledRationalQuadraticSpline(20, 2, 64, 8).cuda().eval()
+    assert not fz.eligible(other.prqct, None)

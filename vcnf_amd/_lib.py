@@ -40,6 +40,10 @@ PROTOTYPES = {
                                ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P], _INT),
     "vcnf_rqs_conditioner_input_f32": ([_P, _I64, _I32, _P, _I32, _P, _I32, _P, _P, _P,
                                         ctypes.POINTER(RqsCfg), _INT, _P, _P], _INT),
+    "vcnf_rqs_layer_fused_pack_floats": ([_I32], _I64),
+    "vcnf_rqs_layer_fused_supported": ([_I32, _I32, _I32, _I32, _I32, _I32, _I32], _INT),
+    "vcnf_rqs_layer_fused_f32": ([_P, _P, _P, _P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _P, _I64,
+                                  _P, _P, _P, ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P], _INT),
     "vcnf_affine_coupling_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _INT, _INT,
                                   _INT, _F32, _P], _INT),
     "vcnf_masked_affine_f32": ([_P, _P, _P, _P, _P, _P, _I64, _I32, _INT, _INT, _F32, _P], _INT),
@@ -239,6 +243,38 @@ def rqs_conditioner_input(x, id_idx, context, shared, cfg, apply_inverse_shared)
                                                   int(bool(apply_inverse_shared)), _ptr(out), _stream())
     _check(st, "vcnf_rqs_conditioner_input_f32")
     return out
+
+
+def rqs_layer_fused(x, context, tf_idx, id_idx, ctx_dim, hidden, num_blocks, wpack, shared, cfg, inverse,
+                    logdet=None, sign=1.0):
+    """Whole coupling layer (conditioner included) in one kernel; see csrc/fused_layer.hip."""
+    dev = require_device(x, context, wpack, logdet, *(shared or ()))
+    b, d = x.shape
+    x = x.contiguous()
+    if context is not None:
+        context = context.contiguous()
+    y = torch.empty_like(x)
+    mode = LD_ACCUM
+    if logdet is None:
+        logdet = torch.empty(b, dtype=torch.float32, device=dev)
+        mode = LD_STORE
+    sw, sh, sd = shared if shared is not None else (None, None, None)
+    sink = EVENT_SINK
+    with torch.cuda.device(dev):
+        if sink is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        st = lib().vcnf_rqs_layer_fused_f32(_ptr(x), _ptr(context), _ptr(y), _ptr(logdet), b,
+                                            _ptr(tf_idx), tf_idx.numel(), _ptr(id_idx), id_idx.numel(),
+                                            int(ctx_dim), int(hidden), int(num_blocks),
+                                            _ptr(wpack), wpack.numel(), _ptr(sw), _ptr(sh), _ptr(sd),
+                                            ctypes.byref(cfg), int(bool(inverse)), mode, float(sign),
+                                            _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
+        if sink is not None:
+            ev1.record()
+            sink.append((ev0, ev1, b))
+    _check(st, "vcnf_rqs_layer_fused_f32")
+    return y, logdet
 
 
 def affine_coupling(z, param, t_off, d_t, scale_map, inverse, logdet=None, sign=1.0):

@@ -1,0 +1,422 @@
+// One whole RQS coupling layer in one kernel: conditioner input gather, the
+// ResidualNet conditioner (dense layers on the fp32 matrix cores), the splines on
+// both halves and the per-sample log|det| - for MI355X (gfx950, wave64).
+//
+// Why: with the layer split into GEMM kernels and a spline kernel, the conditioner
+// output params[B, d_t*(3K-1)] (2944 B per sample at config C3) and ~12 hidden-state
+// tensors cross HBM per layer; fused, a sample costs 4D (x) + 4C (context) + 4D (y)
+// + 8 (log-det) bytes of HBM and everything else stays in registers / LDS.
+//
+// Matrix-core formulation (v_mfma_f32_16x16x4_f32, exact fp32 fma chains):
+//   out^T[N x 16 samples] = W[N x Kin] * in^T[Kin x 16 samples]
+// A operand = weight fragment, lane l holds W[16 nb + (l & 15)][k(l >> 4)];
+// B operand = activations,     lane l holds in[sample l & 15][k(l >> 4)];
+// result: lane l holds out[sample l & 15][16 nb + 4 (l >> 4) + r], r = 0..3.
+// The result registers of one layer are used directly as the B operands of the next
+// one: k-step (nb, r) of the next layer covers k = 16 nb + 4 q + r for lane group
+// q = l >> 4, and the host packs the next layer's weight fragments in that k order.
+// So hidden activations never leave registers.  The last layer's rows are permuted
+// on the host so that lane group q receives all 3K-1 logits of feature 4 g + q
+// (padded to a multiple of 4) in its own registers: the spline is then evaluated
+// straight from the accumulators, with no cross-lane exchange at all.
+//
+// Reference arithmetic: flows/neural_spline/coupling.py:70-125 (layer),
+// nets/resnet.py:38-57, :92-106 (conditioner), utils/splines.py:20-193 (splines).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/vcnf_hip.h"
+#include "rqs_math.hpp"
+
+namespace vcnf {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int kFBlock = 256;     // 4 waves
+constexpr int kCB = 2;           // 16-sample column blocks per wave
+constexpr int kTile = 4 * kCB * 16;   // samples per workgroup tile (128)
+
+struct FusedArgs {
+  const float* x;
+  const float* ctx;
+  float* y;
+  float* logdet;
+  const int32_t* tf_idx;
+  const int32_t* id_idx;
+  const float *sh_w, *sh_h, *sh_d;       // shared (unconditional) spline logits or NULL
+  const float* wpack;                    // packed conditioner weights, layout below
+  unsigned wpack_bytes;
+  int32_t* bad;
+  long long B;
+  int ld_mode;
+  float ld_sign;
+  RqsConst c;
+};
+
+__device__ __forceinline__ floatx4 mfma4(float a, float b, floatx4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte load through a buffer descriptor: address = base + voff (per lane) + soff
+// (wave-uniform, normally a compile-time constant).  All weight traffic goes through
+// one descriptor with the lane part fixed at lane*16, so no load needs 64-bit address
+// arithmetic in vector registers (thousands of fully unrolled loads otherwise spill
+// their precomputed addresses).
+__device__ __forceinline__ floatx4 wload(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+  return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+
+// Packed weight buffer of one layer, in floats (host side: vcnf_amd/fused.py::pack_layer):
+//   W0 [NB][NS0/4][64][4] | b0 [H] | per block: WA [NB][NSH/4][64][4] | ba [H] |
+//   WB [NB][NSH/4][64][4] | bb [H] | (WC [NB][NSC/4][64][4] | bc [H] if C > 0) |
+//   WF [NG][P4][NSH/4][64][4] | bf [NG][4][4*P4]
+template <int DI, int DT, int C, int H, int NBLK, int K>
+struct PackLayout {
+  static constexpr int NB = H / 16, NS0 = (DI + C) / 4, NSH = H / 4, NSC = C / 4;
+  static constexpr int P4 = (3 * K - 1 + 3) / 4, NG = DT / 4;
+  static constexpr int W0 = 0;
+  static constexpr int B0 = W0 + NB * NS0 * 64;
+  static constexpr int BLK0 = B0 + H;
+  static constexpr int WA = 0, BA = WA + NB * NSH * 64, WB = BA + H, BB = WB + NB * NSH * 64;
+  static constexpr int WC = BB + H, BC = WC + NB * NSC * 64;
+  static constexpr int BLK = (C > 0) ? BC + H : WC;           // floats per residual block
+  static constexpr int WF = BLK0 + NBLK * BLK;
+  static constexpr int BF = WF + NG * P4 * NSH * 64;
+  static constexpr int TOTAL = BF + NG * 4 * 4 * P4;
+};
+
+// One 16-row output block of a dense layer for the wave's kCB column blocks:
+//   acc[cb] += sum_s A(s) * B(cb, s),  s < 4 * NS4.
+// The block's weight fragments are packed [s / 4][lane][4]: one 16-byte load per lane
+// feeds 4 k-steps (8 matrix instructions).  B(cb, s) is a callable returning the
+// activation operand (a register of the previous layer's result, optionally ReLU'd).
+template <int NS4, class BOp>
+__device__ __forceinline__ void dense_block(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, BOp bop,
+                                            floatx4 (&acc)[kCB]) {
+  floatx4 a_cur = wload(rsrc, voff, soff);
+#pragma unroll
+  for (int s4 = 0; s4 < NS4; ++s4) {
+    floatx4 a_nxt = a_cur;
+    if (s4 + 1 < NS4) a_nxt = wload(rsrc, voff, soff + (s4 + 1) * 1024);
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+      for (int cb = 0; cb < kCB; ++cb) acc[cb] = mfma4(a_cur[cc], bop(cb, 4 * s4 + cc), acc[cb]);
+    a_cur = a_nxt;
+  }
+}
+
+// bias of row block nb in accumulator layout: lane group q holds rows 16 nb + 4 q + r
+__device__ __forceinline__ void bias_block(__amdgpu_buffer_rsrc_t rsrc, int qoff, int soff, floatx4 (&acc)[kCB]) {
+  const floatx4 v = wload(rsrc, qoff, soff);
+#pragma unroll
+  for (int cb = 0; cb < kCB; ++cb) acc[cb] = v;
+}
+
+// Logits of one element taken straight from accumulator registers: v[t], t = 4 b + r.
+template <int K, int P4>
+struct RegLogits {
+  const floatx4 (&v)[P4];
+  float scale, edge;
+  __device__ __forceinline__ float at(int t) const { return v[t >> 2][t & 3]; }
+  __device__ __forceinline__ float w(int k) const { return at(k); }
+  __device__ __forceinline__ float h(int k) const { return at(K + k); }
+  __device__ __forceinline__ float d(int k) const { return (k == 0 || k == K) ? edge : at(2 * K + k - 1); }
+};
+
+template <int DI, int DT, int C, int H, int NBLK, int K, bool INV>
+__global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const FusedArgs a) {
+  constexpr int D = DI + DT;
+  constexpr int XS = D + 4;                 // padded LDS row strides (16-byte aligned rows)
+  constexpr int CS = (C > 0 ? C : 4) + 4;
+  constexpr int NB = H / 16;                // row blocks of a hidden layer
+  constexpr int NS0 = (DI + C) / 4;         // k-steps of the first layer
+  constexpr int NSH = H / 4;                // k-steps of a hidden->* layer
+  constexpr int NSC = C / 4;
+  constexpr int P = 3 * K - 1;
+  constexpr int P4 = (P + 3) / 4;           // row-block quarters per feature in the last layer
+  constexpr int NG = DT / 4;                // feature groups of the last layer
+  constexpr int TABW = 3 * (K + 1);
+  static_assert(DI % 4 == 0 && DT % 4 == 0 && C % 4 == 0 && H % 16 == 0, "shape family");
+
+  extern __shared__ __align__(16) float smem[];
+  float* xt = smem;                         // [kTile][XS]   x in, y out (in place)
+  float* ct = xt + kTile * XS;              // [kTile][CS]
+  float* tab = ct + kTile * CS;             // [DI][TABW]
+  int* tfi = reinterpret_cast<int*>(tab + ((DI * TABW + 3) & ~3));
+  int* idi = tfi + DT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int m16 = lane & 15;
+  const int q = lane >> 4;
+  const RqsConst& c = a.c;
+  const bool shared = a.sh_w != nullptr;
+
+  for (int i = tid; i < DT; i += kFBlock) tfi[i] = a.tf_idx[i];
+  for (int i = tid; i < DI; i += kFBlock) idi[i] = a.id_idx[i];
+  if (shared) {
+    for (int f = tid; f < DI; f += kFBlock) {
+      SplitLogits p{a.sh_w + f * K, a.sh_h + f * K, a.sh_d + f * (K - 1), K, 1.f, c.edge_logit, c.tails};
+      rqs_build_table(p, c, tab + f * TABW);
+    }
+  }
+
+  const long long ntiles = (a.B + kTile - 1) / kTile;
+  bool bad = false;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long b0 = tile * kTile;
+    const int rows = (int)min((long long)kTile, a.B - b0);
+    __syncthreads();
+    // ---- stage x rows and context rows (coalesced 16-byte loads, padded LDS rows)
+    {
+      constexpr int D4 = D / 4;
+      const float4* sx = reinterpret_cast<const float4*>(a.x) + b0 * D4;
+      for (int i = tid; i < kTile * D4; i += kFBlock) {
+        const int r = i / D4, o = i - r * D4;
+        const float4 v = r < rows ? sx[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(xt + r * XS + 4 * o) = v;
+      }
+      if (C > 0) {
+        constexpr int C4 = (C > 0 ? C : 4) / 4;
+        const float4* sc = reinterpret_cast<const float4*>(a.ctx) + b0 * C4;
+        for (int i = tid; i < kTile * C4; i += kFBlock) {
+          const int r = i / C4, o = i - r * C4;
+          const float4 v = r < rows ? sc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(ct + r * CS + 4 * o) = v;
+        }
+      }
+    }
+    __syncthreads();
+
+    float ld_acc[kCB];
+#pragma unroll
+    for (int cb = 0; cb < kCB; ++cb) ld_acc[cb] = 0.f;
+
+    // ---- identity half through the unconditional spline.  Sampling direction: before
+    // the conditioner (it sees the transformed values, coupling.py:110-114); density
+    // direction: after the operands were read (coupling.py:81-90).
+#define VCNF_IDENTITY_PASS()                                                        \
+  _Pragma("unroll") for (int cb = 0; cb < kCB; ++cb) {                              \
+    const int mi = (wave * kCB + cb) * 16 + m16;                                    \
+    for (int f = q; f < DI; f += 4) {                                               \
+      float* px = xt + mi * XS + idi[f];                                            \
+      const float xv = *px;                                                         \
+      float yv = xv, lad = 0.f;                                                     \
+      if (shared) rqs_point_table<INV>(xv, tab + f * TABW, c, yv, lad, bad);        \
+      *px = yv;                                                                     \
+      ld_acc[cb] += lad;                                                            \
+    }                                                                               \
+  }
+    if (INV) {
+      VCNF_IDENTITY_PASS()
+      __syncthreads();
+    }
+
+    // ---- first-layer operand: identity features then context, natural k order
+    float hin[kCB][NS0];
+#pragma unroll
+    for (int cb = 0; cb < kCB; ++cb) {
+      const int m = (wave * kCB + cb) * 16 + m16;
+#pragma unroll
+      for (int s = 0; s < DI / 4; ++s) hin[cb][s] = xt[m * XS + idi[4 * s + q]];
+#pragma unroll
+      for (int s = 0; s < NSC; ++s) hin[cb][DI / 4 + s] = ct[m * CS + 4 * s + q];
+    }
+    if (!INV) {
+      __syncthreads();
+      VCNF_IDENTITY_PASS()
+    }
+#undef VCNF_IDENTITY_PASS
+
+    // ---- conditioner trunk (nets/resnet.py:92-104); every layer one 16-row block at a time
+    using L = PackLayout<DI, DT, C, H, NBLK, K>;
+    constexpr int NS0_4 = NS0 / 4, NSH_4 = NSH / 4, NSC_4 = (NSC > 0 ? NSC : 4) / 4;
+    const __amdgpu_buffer_rsrc_t wr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpack), 0, a.wpack_bytes, 0x00020000);
+    const int voff = lane * 16;       // fragment loads: 16 bytes per lane
+    const int qoff = q * 16;          // bias loads: 4 consecutive rows per lane group
+    floatx4 h[kCB][NB];
+    auto op_in = [&](int cb, int s) { return hin[cb][s]; };
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      floatx4 acc[kCB];
+      bias_block(wr, qoff, 4 * (L::B0 + 16 * nb), acc);
+      dense_block<NS0_4>(wr, voff, 4 * (L::W0 + nb * NS0 * 64), op_in, acc);
+#pragma unroll
+      for (int cb = 0; cb < kCB; ++cb) h[cb][nb] = acc[cb];
+    }
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk) {
+      const int base = L::BLK0 + blk * L::BLK;
+      floatx4 t[kCB][NB];
+      auto op_h = [&](int cb, int s) { return fmaxf(h[cb][s >> 2][s & 3], 0.f); };      // resnet.py:42
+      auto op_t = [&](int cb, int s) { return fmaxf(t[cb][s >> 2][s & 3], 0.f); };      // :46
+      auto op_c = [&](int cb, int s) { return hin[cb][DI / 4 + s]; };
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {                                                // :43
+        floatx4 acc[kCB];
+        bias_block(wr, qoff, 4 * (base + L::BA + 16 * nb), acc);
+        dense_block<NSH_4>(wr, voff, 4 * (base + L::WA + nb * NSH * 64), op_h, acc);
+#pragma unroll
+        for (int cb = 0; cb < kCB; ++cb) t[cb][nb] = acc[cb];
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {                                                // :48-57
+        floatx4 acc[kCB];
+        bias_block(wr, qoff, 4 * (base + L::BB + 16 * nb), acc);
+        dense_block<NSH_4>(wr, voff, 4 * (base + L::WB + nb * NSH * 64), op_t, acc);
+        if (C > 0) {                                                                   // GLU gate
+          floatx4 gate[kCB];
+          bias_block(wr, qoff, 4 * (base + L::BC + 16 * nb), gate);
+          dense_block<NSC_4>(wr, voff, 4 * (base + L::WC + nb * (NSC > 0 ? NSC : 4) * 64), op_c, gate);
+#pragma unroll
+          for (int cb = 0; cb < kCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float sg = div_nr(1.f, 1.f + hw_exp2(-gate[cb][r] * kLog2e));
+              h[cb][nb][r] = fmaf(acc[cb][r], sg, h[cb][nb][r]);
+            }
+        } else {
+#pragma unroll
+          for (int cb = 0; cb < kCB; ++cb) h[cb][nb] += acc[cb];
+        }
+      }
+    }
+
+    // ---- last layer + splines, 4 features (one per lane group) at a time
+    auto op_f = [&](int cb, int s) { return h[cb][s >> 2][s & 3]; };
+    for (int g = 0; g < NG; ++g) {
+      floatx4 pa[kCB][P4];
+#pragma unroll
+      for (int b = 0; b < P4; ++b) {                                                   // resnet.py:105
+        floatx4 acc[kCB];
+        bias_block(wr, q * (16 * P4), 4 * (L::BF + g * 4 * (4 * P4) + 4 * b), acc);   // bf[g][q][4b..4b+3]
+        dense_block<NSH_4>(wr, voff, 4 * (L::WF + (g * P4 + b) * NSH * 64), op_f, acc);
+#pragma unroll
+        for (int cb = 0; cb < kCB; ++cb) pa[cb][b] = acc[cb];
+      }
+      const int col = tfi[4 * g + q];
+#pragma unroll
+      for (int cb = 0; cb < kCB; ++cb) {
+        const int m = (wave * kCB + cb) * 16 + m16;
+        float* px = xt + m * XS + col;
+        const float xv = *px;
+        RegLogits<K, P4> p{pa[cb], c.wh_scale, c.edge_logit};
+        float yv, lad;
+        if (c.tails == 1 && !((xv >= c.lo_x) && (xv <= c.hi_x))) {
+          yv = xv;
+          lad = 0.f;
+        } else {
+          RqsBin sel;
+          rqs_select<K, INV>(xv, p, c, c.wh_scale * kLog2e, sel);
+          rqs_bin_eval<INV>(xv, sel, yv, lad, bad);
+        }
+        *px = yv;
+        ld_acc[cb] += lad;
+      }
+    }
+
+    // ---- per-sample log|det|: the 4 lane groups of a sample, then one store
+#pragma unroll
+    for (int cb = 0; cb < kCB; ++cb) {
+      float v = ld_acc[cb];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int m = (wave * kCB + cb) * 16 + m16;
+      if (q == 0 && m < rows) {
+        const float o = a.ld_sign * v;
+        a.logdet[b0 + m] = a.ld_mode ? a.logdet[b0 + m] + o : o;
+      }
+    }
+    __syncthreads();
+    {
+      constexpr int D4 = D / 4;
+      float4* dst = reinterpret_cast<float4*>(a.y) + b0 * D4;
+      for (int i = tid; i < rows * D4; i += kFBlock) {
+        const int r = i / D4, o = i - r * D4;
+        dst[i] = *reinterpret_cast<const float4*>(xt + r * XS + 4 * o);
+      }
+    }
+  }
+  if (INV && a.bad && bad) atomicAdd(a.bad, 1);
+}
+
+template <int DI, int DT, int C, int H, int NBLK, int K>
+static int launch_fused(const FusedArgs& a, int inverse, hipStream_t st) {
+  constexpr int D = DI + DT;
+  const size_t lds = ((size_t)kTile * (D + 4) + (size_t)kTile * ((C > 0 ? C : 4) + 4) +
+                      ((DI * 3 * (K + 1) + 3) & ~3) + D) * 4 + 64;
+  const long long ntiles = (a.B + kTile - 1) / kTile;
+  dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512));
+  if (inverse)
+    hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, true>), grid, dim3(kFBlock), lds, st, a);
+  else
+    hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, false>), grid, dim3(kFBlock), lds, st, a);
+  return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
+}
+
+}  // namespace vcnf
+
+using namespace vcnf;
+
+extern "C" int64_t vcnf_rqs_layer_fused_pack_floats(int32_t ctx_dim) {
+  return ctx_dim == 16 ? PackLayout<32, 32, 16, 128, 2, 8>::TOTAL : PackLayout<32, 32, 0, 128, 2, 8>::TOTAL;
+}
+
+extern "C" int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t ctx_dim, int32_t hidden,
+                                              int32_t num_blocks, int32_t num_bins, int32_t tails) {
+  if (tails != VCNF_TAILS_LINEAR || num_bins != 8 || hidden != 128 || num_blocks != 2) return 0;
+  if (d_id == 32 && d_t == 32 && (ctx_dim == 16 || ctx_dim == 0)) return 1;
+  return 0;
+}
+
+extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, float* logdet,
+                                        int64_t batch, const int32_t* transform_idx, int32_t d_t,
+                                        const int32_t* identity_idx, int32_t d_id, int32_t ctx_dim,
+                                        int32_t hidden, int32_t num_blocks,
+                                        const float* wpack, int64_t wpack_floats,
+                                        const float* shared_w, const float* shared_h, const float* shared_d,
+                                        const vcnf_rqs_cfg* cfg, int inverse,
+                                        int ld_mode, float ld_sign, int32_t* bad_disc, void* stream) {
+  if (!cfg || !wpack) return VCNF_ERR_NULL;
+  if (!vcnf_rqs_layer_fused_supported(d_id, d_t, ctx_dim, hidden, num_blocks, cfg->num_bins, cfg->tails))
+    return VCNF_ERR_UNSUPPORTED;
+  if (batch < 0) return VCNF_ERR_SHAPE;
+  if (batch == 0) return VCNF_OK;
+  if (!x || !y || !logdet || !transform_idx || !identity_idx || (ctx_dim > 0 && !context)) return VCNF_ERR_NULL;
+  const bool any_sh = shared_w || shared_h || shared_d;
+  if (any_sh && !(shared_w && shared_h && shared_d)) return VCNF_ERR_NULL;
+  if (ld_mode != VCNF_LD_STORE && ld_mode != VCNF_LD_ACCUM) return VCNF_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(context)) & 15)
+    return VCNF_ERR_ALIGN;
+  if ((double)cfg->min_bin_width * cfg->num_bins > 1.0 || (double)cfg->min_bin_height * cfg->num_bins > 1.0)
+    return VCNF_ERR_VALUE;
+
+  FusedArgs a;
+  a.x = x; a.ctx = context; a.y = y; a.logdet = logdet;
+  a.tf_idx = transform_idx; a.id_idx = identity_idx;
+  a.sh_w = shared_w; a.sh_h = shared_h; a.sh_d = shared_d;
+  a.wpack = wpack; a.wpack_bytes = (unsigned)(wpack_floats * 4);
+  a.bad = bad_disc; a.B = batch; a.ld_mode = ld_mode; a.ld_sign = ld_sign;
+  const int K = cfg->num_bins;
+  a.c.K = K; a.c.tails = cfg->tails;
+  a.c.lo_x = cfg->left; a.c.hi_x = cfg->right; a.c.span_x = (float)((double)cfg->right - (double)cfg->left);
+  a.c.lo_y = cfg->bottom; a.c.hi_y = cfg->top; a.c.span_y = (float)((double)cfg->top - (double)cfg->bottom);
+  a.c.min_w = cfg->min_bin_width; a.c.min_h = cfg->min_bin_height; a.c.min_d = cfg->min_derivative;
+  a.c.free_w = (float)(1.0 - (double)cfg->min_bin_width * K);
+  a.c.free_h = (float)(1.0 - (double)cfg->min_bin_height * K);
+  a.c.wh_scale = cfg->wh_scale;
+  a.c.edge_logit = (float)log(exp(1.0 - (double)cfg->min_derivative) - 1.0);
+  hipStream_t st = (hipStream_t)stream;
+  if (ctx_dim == 16) {
+    if (wpack_floats != PackLayout<32, 32, 16, 128, 2, 8>::TOTAL) return VCNF_ERR_SHAPE;
+    return launch_fused<32, 32, 16, 128, 2, 8>(a, inverse, st);
+  }
+  if (wpack_floats != PackLayout<32, 32, 0, 128, 2, 8>::TOTAL) return VCNF_ERR_SHAPE;
+  return launch_fused<32, 32, 0, 128, 2, 8>(a, inverse, st);
+}

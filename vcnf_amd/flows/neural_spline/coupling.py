@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from ..base import Flow
-from ... import _lib
+from ... import _lib, fused
 from ...utils import splines
 
 
@@ -127,6 +127,9 @@ class PiecewiseRationalQuadraticCoupling(Flow):
         else:
             self.unconditional_transform = None
         self._i32 = {}
+        # use the single-kernel layer when shape and conditioner qualify (fused.eligible);
+        # set False to force the three-step path (gather kernel, torch GEMMs, spline kernel)
+        self.fused = True
 
     @property
     def num_identity_features(self):
@@ -189,6 +192,9 @@ class PiecewiseRationalQuadraticCoupling(Flow):
 
     def _run(self, inputs, context, sampling, log_q=None, sign=1.0):
         self._check(inputs)
+        if self.fused and fused.eligible(self, context):
+            # conditioner + splines in one kernel (csrc/fused_layer.hip)
+            return fused.run(self, inputs, context, sampling, log_q, sign)
         params = self._params(inputs, context, sampling)
         expect = self.num_transform_features * self._transform_dim_multiplier()
         if params.dim() != 2 or params.shape[1] != expect:
