@@ -41,8 +41,12 @@ from vcnf_amd import _lib        # noqa: E402
 
 D, CTX, LAYERS, HIDDEN, BLOCKS, BINS, TAIL = 64, 16, 12, 128, 2, 8, 3.0
 HBM_PEAK = 8.0e12                                   # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK = 157.3e12                            # MI355X_MICROARCH.md: dense fp32 matrix peak
 P = 3 * BINS - 1
 BYTES_PER_SAMPLE_LAYER = 4 * D + 4 * (D // 2) * P + 4 * D + 8     # 3464, SURVEY 8(d)
+# conditioner flop per sample-layer (339 968): 2 * (48*128 + 4*128*128 + 2*16*128 + 128*736)
+FLOP_PER_SAMPLE_LAYER = 2 * ((D // 2 + CTX) * HIDDEN + 2 * BLOCKS * HIDDEN * HIDDEN +
+                             BLOCKS * CTX * HIDDEN + HIDDEN * (D // 2) * P)
 
 
 def build_model(device, seed=0):
@@ -59,6 +63,28 @@ def build_model(device, seed=0):
             if "unnormalized_" in n:
                 p.normal_(0.0, 0.5)
     return model.to(device).eval()
+
+
+def pmc_traffic(kernel, batch):
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of this
+    same command (profiles/*_pmc_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs,
+    gfx950 correction applied there).  bench.py cannot collect counters itself; null when
+    no measurement for this kernel and batch size is on file."""
+    best = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        if not name.endswith("_pmc_hbm_traffic.json"):
+            continue
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        if rec.get("batch_per_launch") != batch:
+            continue
+        vals = [v["hbm_bytes_per_launch"] for k, v in rec.get("kernels", {}).items()
+                if kernel in k and "hbm_bytes_per_launch" in v]
+        if vals:
+            best = int(sum(vals) / len(vals))
+    return best
 
 
 def cpu_baseline(model, budget_s=20.0):
@@ -97,6 +123,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1 << 20, help="samples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split", action="store_true",
+                    help="three-step layers (gather kernel, torch GEMMs, spline kernel) instead of the fused kernel")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,6 +141,8 @@ def main():
     nf.lib()
 
     model = build_model(device, seed=0)                      # replicated weights
+    for f in model.flows:
+        f.prqct.fused = not args.split
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
     B = args.batch
     x = torch.randn(B, D, device=device, generator=gen)
@@ -152,10 +182,45 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    # dominant kernel: mean duration of the RQS coupling launches inside the timed region
+    # dominant kernel: mean launch duration inside the timed region (HIP events on the launch stream).
+    # Fused layers: one kernel per layer does conditioner + splines and is bound by the fp32 matrix
+    # cores; split layers: the spline kernel streams params from HBM and is HBM-bound.
     durs = [a.elapsed_time(b) * 1e-3 for a, b, _ in events]
     kern_s = sum(durs) / max(len(durs), 1)
-    achieved = BYTES_PER_SAMPLE_LAYER * B / kern_s if durs else 0.0
+    if args.split:
+        work, peak, unit, bound, kname = BYTES_PER_SAMPLE_LAYER * B, HBM_PEAK, "GB/s", "hbm", "rqs_coupling_pf_kernel"
+        note = "algorithmic bytes 3464 B/sample-layer (x + params + y + logdet)"
+    else:
+        work, peak, unit, bound, kname = FLOP_PER_SAMPLE_LAYER * B, MFMA_F32_PEAK, "TFLOP/s", "mfma", "fused_rqs_layer_kernel"
+        note = ("algorithmic flop %d per sample-layer (conditioner GEMMs); HBM side of the same launch: "
+                "%d B/sample-layer" % (FLOP_PER_SAMPLE_LAYER, 4 * D + 4 * CTX + 4 * D + 8))
+    achieved = work / kern_s if durs else 0.0
+    scale = 1e9 if unit == "GB/s" else 1e12
+    traffic = pmc_traffic(kname, B)
+
+    # the HBM-bound spline kernel on its own (outside the timed region): one layer evaluated
+    # through the three-step path with the conditioner output materialised, spline launch timed
+    hbm_side = None
+    if rank == 0 and not args.split:
+        lay = model.flows[0].prqct
+        with torch.no_grad():
+            params = lay._params(x, ctx, False)
+            shared = lay.unconditional_transform.logits()
+            tf, idf, cfg = lay._index32('tf'), lay._index32('id'), lay._cfg(True)
+            for _ in range(2):
+                _lib.rqs_coupling(x, params, tf, idf, shared, cfg, False)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                _lib.rqs_coupling(x, params, tf, idf, shared, cfg, False)
+            e1.record()
+            torch.cuda.synchronize()
+            t_sp = e0.elapsed_time(e1) * 1e-4
+            del params
+        hbm_side = {"kernel": "rqs_coupling_pf_kernel (split path, not in the timed region)",
+                    "achieved": round(BYTES_PER_SAMPLE_LAYER * B / t_sp / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s", "frac": round(BYTES_PER_SAMPLE_LAYER * B / t_sp / HBM_PEAK, 4),
+                    "avg_launch_ms": round(t_sp * 1e3, 4)}
 
     if rank == 0:
         transforms = 2.0 * B * args.steps * world
@@ -171,12 +236,14 @@ def main():
                                    "(8 bins), batch=%d per GPU, log_prob + sample per step" % B,
                        "batch_per_gpu": B, "layers": LAYERS, "bins": BINS, "hidden": HIDDEN,
                        "sharding": "batch over %d GPU(s), one all-reduce of [sum log_prob, count]" % world},
-            "roofline": {"bound": "hbm", "kernel": "rqs_coupling_kernel",
-                         "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+            "roofline": {"bound": bound, "kernel": kname,
+                         "achieved": round(achieved / scale, 1), "peak": peak / scale, "unit": unit,
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
                          "launches": len(durs), "avg_launch_ms": round(kern_s * 1e3, 4),
-                         "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE_LAYER * B},
+                         "algorithmic_work_per_launch": work, "note": note},
         }
+        if hbm_side is not None:
+            out["roofline_hbm_spline_kernel"] = hbm_side
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(out))
