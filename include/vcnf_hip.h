@@ -45,6 +45,7 @@ enum {
 
 enum { VCNF_LD_STORE = 0, VCNF_LD_ACCUM = 1 };
 enum { VCNF_TAILS_NONE = 0, VCNF_TAILS_LINEAR = 1 };
+enum { VCNF_PREC_F32 = 0, VCNF_PREC_F16X3 = 1 };   /* matrix path of the fused layer kernel */
 enum { VCNF_SCALE_EXP = 0, VCNF_SCALE_SIGMOID = 1, VCNF_SCALE_SIGMOID_INV = 2, VCNF_SCALE_NONE = 3 };
 
 int vcnf_abi_version(void);
@@ -124,11 +125,16 @@ int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t ctx_dim, i
  * evaluated on the fp32 matrix cores.  Same results contract as
  * vcnf_rqs_conditioner_input_f32 + the dense layers + vcnf_rqs_coupling_f32; the
  * conditioner output never touches HBM.  context[B, ctx_dim] may be NULL when
- * ctx_dim = 0.  x, y, context must be 16-byte aligned. */
+ * ctx_dim = 0.  x, y, context must be 16-byte aligned.
+ * precision: VCNF_PREC_F32 - every dense layer on v_mfma_f32_16x16x4_f32 (exact fp32
+ * fma chains); VCNF_PREC_F16X3 - the hidden->hidden and last layers on the fp16 matrix
+ * instruction with operands split into hi + lo*2^-11 halves (22 significant bits, 3
+ * instructions per product; hidden activations must stay below 65504 in magnitude);
+ * wpack must have been packed for the same precision. */
 int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, float* logdet,
                              int64_t batch, const int32_t* transform_idx, int32_t d_t,
                              const int32_t* identity_idx, int32_t d_id, int32_t ctx_dim,
-                             int32_t hidden, int32_t num_blocks,
+                             int32_t hidden, int32_t num_blocks, int32_t precision,
                              const float* wpack, int64_t wpack_floats,
                              const float* shared_w, const float* shared_h, const float* shared_d,
                              const vcnf_rqs_cfg* cfg, int inverse,

@@ -42,7 +42,7 @@ PROTOTYPES = {
                                         ctypes.POINTER(RqsCfg), _INT, _P, _P], _INT),
     "vcnf_rqs_layer_fused_pack_floats": ([_I32], _I64),
     "vcnf_rqs_layer_fused_supported": ([_I32, _I32, _I32, _I32, _I32, _I32, _I32], _INT),
-    "vcnf_rqs_layer_fused_f32": ([_P, _P, _P, _P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _P, _I64,
+    "vcnf_rqs_layer_fused_f32": ([_P, _P, _P, _P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _I64,
                                   _P, _P, _P, ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P], _INT),
     "vcnf_affine_coupling_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _INT, _INT,
                                   _INT, _F32, _P], _INT),
@@ -245,8 +245,8 @@ def rqs_conditioner_input(x, id_idx, context, shared, cfg, apply_inverse_shared)
     return out
 
 
-def rqs_layer_fused(x, context, tf_idx, id_idx, ctx_dim, hidden, num_blocks, wpack, shared, cfg, inverse,
-                    logdet=None, sign=1.0):
+def rqs_layer_fused(x, context, tf_idx, id_idx, ctx_dim, hidden, num_blocks, precision, wpack, shared, cfg,
+                    inverse, logdet=None, sign=1.0):
     """Whole coupling layer (conditioner included) in one kernel; see csrc/fused_layer.hip."""
     dev = require_device(x, context, wpack, logdet, *(shared or ()))
     b, d = x.shape
@@ -266,7 +266,7 @@ def rqs_layer_fused(x, context, tf_idx, id_idx, ctx_dim, hidden, num_blocks, wpa
             ev0.record()
         st = lib().vcnf_rqs_layer_fused_f32(_ptr(x), _ptr(context), _ptr(y), _ptr(logdet), b,
                                             _ptr(tf_idx), tf_idx.numel(), _ptr(id_idx), id_idx.numel(),
-                                            int(ctx_dim), int(hidden), int(num_blocks),
+                                            int(ctx_dim), int(hidden), int(num_blocks), int(precision),
                                             _ptr(wpack), wpack.numel(), _ptr(sw), _ptr(sh), _ptr(sd),
                                             ctypes.byref(cfg), int(bool(inverse)), mode, float(sign),
                                             _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())

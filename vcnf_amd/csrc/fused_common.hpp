@@ -1,0 +1,83 @@
+// Shared pieces of the fused RQS-layer kernels (fused_layer.hip: exact fp32 matrix path;
+// fused_layer_v2.hip: fp16x3 split-half matrix path).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rqs_math.hpp"
+
+namespace vcnf {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int kFBlock = 256;     // 4 waves; each wave owns kCB 16-sample column blocks of the tile
+
+struct FusedArgs {
+  const float* x;
+  const float* ctx;
+  float* y;
+  float* logdet;
+  const int32_t* tf_idx;
+  const int32_t* id_idx;
+  const float *sh_w, *sh_h, *sh_d;       // shared (unconditional) spline logits or NULL
+  const float* wpack;                    // packed conditioner weights, layout below
+  unsigned wpack_bytes;
+  int32_t* bad;
+  long long B;
+  int ld_mode;
+  float ld_sign;
+  int dbg;                               // scratch experiments only (VCNF_DBG env)
+  RqsConst c;
+};
+
+__device__ __forceinline__ floatx4 mfma4(float a, float b, floatx4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte load through a buffer descriptor: address = base + voff (per lane) + soff
+// (wave-uniform, normally a compile-time constant).  All weight traffic goes through
+// one descriptor with the lane part fixed at lane*16, so no load needs 64-bit address
+// arithmetic in vector registers (thousands of fully unrolled loads otherwise spill
+// their precomputed addresses).
+__device__ __forceinline__ floatx4 wload(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+  return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+
+// Packed weight buffer of one layer, in floats (host side: vcnf_amd/fused.py::pack_layer):
+//   W0 [NB][NS0/4][64][4] | b0 [H] | per block: WA [NB][NSH/4][64][4] | ba [H] |
+//   WB [NB][NSH/4][64][4] | bb [H] | (WC [NB][NSC/4][64][4] | bc [H] if C > 0) |
+//   WF [NG][P4][NSH/4][64][4] | bf [NG][4][4*P4]
+template <int DI, int DT, int C, int H, int NBLK, int K>
+struct PackLayout {
+  static constexpr int NB = H / 16, NS0 = (DI + C) / 4, NSH = H / 4, NSC = C / 4;
+  static constexpr int P4 = (3 * K - 1 + 3) / 4, NG = DT / 4;
+  static constexpr int W0 = 0;
+  static constexpr int B0 = W0 + NB * NS0 * 64;
+  static constexpr int BLK0 = B0 + H;
+  static constexpr int WA = 0, BA = WA + NB * NSH * 64, WB = BA + H, BB = WB + NB * NSH * 64;
+  static constexpr int WC = BB + H, BC = WC + NB * NSC * 64;
+  static constexpr int BLK = (C > 0) ? BC + H : WC;           // floats per residual block
+  static constexpr int WF = BLK0 + NBLK * BLK;
+  static constexpr int BF = WF + NG * P4 * NSH * 64;
+  static constexpr int TOTAL = BF + NG * 4 * 4 * P4;
+};
+
+// Logits of one element taken straight from accumulator registers: v[t], t = 4 b + r.
+template <int K, int P4>
+struct RegLogits {
+  const floatx4 (&v)[P4];
+  float scale, edge;
+  __device__ __forceinline__ float at(int t) const { return v[t >> 2][t & 3]; }
+  __device__ __forceinline__ float w(int k) const { return at(k); }
+  __device__ __forceinline__ float h(int k) const { return at(K + k); }
+  __device__ __forceinline__ float d(int k) const { return (k == 0 || k == K) ? edge : at(2 * K + k - 1); }
+};
+
+
+// defined in fused_layer_v2.hip
+int launch_fused_v2_c16(const FusedArgs& a, int inverse, hipStream_t st);
+int launch_fused_v2_c0(const FusedArgs& a, int inverse, hipStream_t st);
+
+}  // namespace vcnf

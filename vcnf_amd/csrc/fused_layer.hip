@@ -28,72 +28,16 @@
 
 #include "../../include/vcnf_hip.h"
 #include "rqs_math.hpp"
+#include "fused_common.hpp"
 
 namespace vcnf {
-
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-constexpr int kFBlock = 256;     // 4 waves
-constexpr int kCB = 2;           // 16-sample column blocks per wave
-constexpr int kTile = 4 * kCB * 16;   // samples per workgroup tile (128)
-
-struct FusedArgs {
-  const float* x;
-  const float* ctx;
-  float* y;
-  float* logdet;
-  const int32_t* tf_idx;
-  const int32_t* id_idx;
-  const float *sh_w, *sh_h, *sh_d;       // shared (unconditional) spline logits or NULL
-  const float* wpack;                    // packed conditioner weights, layout below
-  unsigned wpack_bytes;
-  int32_t* bad;
-  long long B;
-  int ld_mode;
-  float ld_sign;
-  RqsConst c;
-};
-
-__device__ __forceinline__ floatx4 mfma4(float a, float b, floatx4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// 16-byte load through a buffer descriptor: address = base + voff (per lane) + soff
-// (wave-uniform, normally a compile-time constant).  All weight traffic goes through
-// one descriptor with the lane part fixed at lane*16, so no load needs 64-bit address
-// arithmetic in vector registers (thousands of fully unrolled loads otherwise spill
-// their precomputed addresses).
-__device__ __forceinline__ floatx4 wload(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
-  return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
-}
-
-// Packed weight buffer of one layer, in floats (host side: vcnf_amd/fused.py::pack_layer):
-//   W0 [NB][NS0/4][64][4] | b0 [H] | per block: WA [NB][NSH/4][64][4] | ba [H] |
-//   WB [NB][NSH/4][64][4] | bb [H] | (WC [NB][NSC/4][64][4] | bc [H] if C > 0) |
-//   WF [NG][P4][NSH/4][64][4] | bf [NG][4][4*P4]
-template <int DI, int DT, int C, int H, int NBLK, int K>
-struct PackLayout {
-  static constexpr int NB = H / 16, NS0 = (DI + C) / 4, NSH = H / 4, NSC = C / 4;
-  static constexpr int P4 = (3 * K - 1 + 3) / 4, NG = DT / 4;
-  static constexpr int W0 = 0;
-  static constexpr int B0 = W0 + NB * NS0 * 64;
-  static constexpr int BLK0 = B0 + H;
-  static constexpr int WA = 0, BA = WA + NB * NSH * 64, WB = BA + H, BB = WB + NB * NSH * 64;
-  static constexpr int WC = BB + H, BC = WC + NB * NSC * 64;
-  static constexpr int BLK = (C > 0) ? BC + H : WC;           // floats per residual block
-  static constexpr int WF = BLK0 + NBLK * BLK;
-  static constexpr int BF = WF + NG * P4 * NSH * 64;
-  static constexpr int TOTAL = BF + NG * 4 * 4 * P4;
-};
 
 // One 16-row output block of a dense layer for the wave's kCB column blocks:
 //   acc[cb] += sum_s A(s) * B(cb, s),  s < 4 * NS4.
 // The block's weight fragments are packed [s / 4][lane][4]: one 16-byte load per lane
 // feeds 4 k-steps (8 matrix instructions).  B(cb, s) is a callable returning the
 // activation operand (a register of the previous layer's result, optionally ReLU'd).
-template <int NS4, class BOp>
+template <int NS4, int kCB, class BOp>
 __device__ __forceinline__ void dense_block(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, BOp bop,
                                             floatx4 (&acc)[kCB]) {
   floatx4 a_cur = wload(rsrc, voff, soff);
@@ -110,25 +54,16 @@ __device__ __forceinline__ void dense_block(__amdgpu_buffer_rsrc_t rsrc, int vof
 }
 
 // bias of row block nb in accumulator layout: lane group q holds rows 16 nb + 4 q + r
+template <int kCB>
 __device__ __forceinline__ void bias_block(__amdgpu_buffer_rsrc_t rsrc, int qoff, int soff, floatx4 (&acc)[kCB]) {
   const floatx4 v = wload(rsrc, qoff, soff);
 #pragma unroll
   for (int cb = 0; cb < kCB; ++cb) acc[cb] = v;
 }
 
-// Logits of one element taken straight from accumulator registers: v[t], t = 4 b + r.
-template <int K, int P4>
-struct RegLogits {
-  const floatx4 (&v)[P4];
-  float scale, edge;
-  __device__ __forceinline__ float at(int t) const { return v[t >> 2][t & 3]; }
-  __device__ __forceinline__ float w(int k) const { return at(k); }
-  __device__ __forceinline__ float h(int k) const { return at(K + k); }
-  __device__ __forceinline__ float d(int k) const { return (k == 0 || k == K) ? edge : at(2 * K + k - 1); }
-};
-
-template <int DI, int DT, int C, int H, int NBLK, int K, bool INV>
+template <int DI, int DT, int C, int H, int NBLK, int K, bool INV, int kCB>
 __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const FusedArgs a) {
+  constexpr int kTile = 4 * kCB * 16;       // samples per workgroup tile
   constexpr int D = DI + DT;
   constexpr int XS = D + 4;                 // padded LDS row strides (16-byte aligned rows)
   constexpr int CS = (C > 0 ? C : 4) + 4;
@@ -246,7 +181,7 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
     for (int nb = 0; nb < NB; ++nb) {
       floatx4 acc[kCB];
       bias_block(wr, qoff, 4 * (L::B0 + 16 * nb), acc);
-      dense_block<NS0_4>(wr, voff, 4 * (L::W0 + nb * NS0 * 64), op_in, acc);
+      dense_block<NS0_4, kCB>(wr, voff, 4 * (L::W0 + nb * NS0 * 64), op_in, acc);
 #pragma unroll
       for (int cb = 0; cb < kCB; ++cb) h[cb][nb] = acc[cb];
     }
@@ -254,14 +189,15 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
     for (int blk = 0; blk < NBLK; ++blk) {
       const int base = L::BLK0 + blk * L::BLK;
       floatx4 t[kCB][NB];
+      // context operand re-read from the LDS tile (keeps 2*C/4 registers free across the block)
+      auto op_c = [&](int cb, int s) { return ct[((wave * kCB + cb) * 16 + m16) * CS + 4 * s + q]; };
       auto op_h = [&](int cb, int s) { return fmaxf(h[cb][s >> 2][s & 3], 0.f); };      // resnet.py:42
       auto op_t = [&](int cb, int s) { return fmaxf(t[cb][s >> 2][s & 3], 0.f); };      // :46
-      auto op_c = [&](int cb, int s) { return hin[cb][DI / 4 + s]; };
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {                                                // :43
         floatx4 acc[kCB];
         bias_block(wr, qoff, 4 * (base + L::BA + 16 * nb), acc);
-        dense_block<NSH_4>(wr, voff, 4 * (base + L::WA + nb * NSH * 64), op_h, acc);
+        dense_block<NSH_4, kCB>(wr, voff, 4 * (base + L::WA + nb * NSH * 64), op_h, acc);
 #pragma unroll
         for (int cb = 0; cb < kCB; ++cb) t[cb][nb] = acc[cb];
       }
@@ -269,11 +205,11 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
       for (int nb = 0; nb < NB; ++nb) {                                                // :48-57
         floatx4 acc[kCB];
         bias_block(wr, qoff, 4 * (base + L::BB + 16 * nb), acc);
-        dense_block<NSH_4>(wr, voff, 4 * (base + L::WB + nb * NSH * 64), op_t, acc);
+        dense_block<NSH_4, kCB>(wr, voff, 4 * (base + L::WB + nb * NSH * 64), op_t, acc);
         if (C > 0) {                                                                   // GLU gate
           floatx4 gate[kCB];
           bias_block(wr, qoff, 4 * (base + L::BC + 16 * nb), gate);
-          dense_block<NSC_4>(wr, voff, 4 * (base + L::WC + nb * (NSC > 0 ? NSC : 4) * 64), op_c, gate);
+          dense_block<NSC_4, kCB>(wr, voff, 4 * (base + L::WC + nb * (NSC > 0 ? NSC : 4) * 64), op_c, gate);
 #pragma unroll
           for (int cb = 0; cb < kCB; ++cb)
 #pragma unroll
@@ -296,7 +232,7 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
       for (int b = 0; b < P4; ++b) {                                                   // resnet.py:105
         floatx4 acc[kCB];
         bias_block(wr, q * (16 * P4), 4 * (L::BF + g * 4 * (4 * P4) + 4 * b), acc);   // bf[g][q][4b..4b+3]
-        dense_block<NSH_4>(wr, voff, 4 * (L::WF + (g * P4 + b) * NSH * 64), op_f, acc);
+        dense_block<NSH_4, kCB>(wr, voff, 4 * (L::WF + (g * P4 + b) * NSH * 64), op_f, acc);
 #pragma unroll
         for (int cb = 0; cb < kCB; ++cb) pa[cb][b] = acc[cb];
       }
@@ -346,17 +282,19 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
   if (INV && a.bad && bad) atomicAdd(a.bad, 1);
 }
 
-template <int DI, int DT, int C, int H, int NBLK, int K>
+template <int DI, int DT, int C, int H, int NBLK, int K, int kCB>
 static int launch_fused(const FusedArgs& a, int inverse, hipStream_t st) {
+  constexpr int kTile = 4 * kCB * 16;
   constexpr int D = DI + DT;
   const size_t lds = ((size_t)kTile * (D + 4) + (size_t)kTile * ((C > 0 ? C : 4) + 4) +
                       ((DI * 3 * (K + 1) + 3) & ~3) + D) * 4 + 64;
   const long long ntiles = (a.B + kTile - 1) / kTile;
-  dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512));
+  const long long resident = 256 * 2;   // workgroups the chip holds at once
+  dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
   if (inverse)
-    hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, true>), grid, dim3(kFBlock), lds, st, a);
+    hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, true, kCB>), grid, dim3(kFBlock), lds, st, a);
   else
-    hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, false>), grid, dim3(kFBlock), lds, st, a);
+    hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, false, kCB>), grid, dim3(kFBlock), lds, st, a);
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }
 
@@ -378,7 +316,7 @@ extern "C" int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t
 extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, float* logdet,
                                         int64_t batch, const int32_t* transform_idx, int32_t d_t,
                                         const int32_t* identity_idx, int32_t d_id, int32_t ctx_dim,
-                                        int32_t hidden, int32_t num_blocks,
+                                        int32_t hidden, int32_t num_blocks, int32_t precision,
                                         const float* wpack, int64_t wpack_floats,
                                         const float* shared_w, const float* shared_h, const float* shared_d,
                                         const vcnf_rqs_cfg* cfg, int inverse,
@@ -386,6 +324,7 @@ extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, fl
   if (!cfg || !wpack) return VCNF_ERR_NULL;
   if (!vcnf_rqs_layer_fused_supported(d_id, d_t, ctx_dim, hidden, num_blocks, cfg->num_bins, cfg->tails))
     return VCNF_ERR_UNSUPPORTED;
+  if (precision != VCNF_PREC_F32 && precision != VCNF_PREC_F16X3) return VCNF_ERR_UNSUPPORTED;
   if (batch < 0) return VCNF_ERR_SHAPE;
   if (batch == 0) return VCNF_OK;
   if (!x || !y || !logdet || !transform_idx || !identity_idx || (ctx_dim > 0 && !context)) return VCNF_ERR_NULL;
@@ -403,6 +342,7 @@ extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, fl
   a.sh_w = shared_w; a.sh_h = shared_h; a.sh_d = shared_d;
   a.wpack = wpack; a.wpack_bytes = (unsigned)(wpack_floats * 4);
   a.bad = bad_disc; a.B = batch; a.ld_mode = ld_mode; a.ld_sign = ld_sign;
+  { const char* e = getenv("VCNF_DBG"); a.dbg = e ? atoi(e) : 0; }
   const int K = cfg->num_bins;
   a.c.K = K; a.c.tails = cfg->tails;
   a.c.lo_x = cfg->left; a.c.hi_x = cfg->right; a.c.span_x = (float)((double)cfg->right - (double)cfg->left);
@@ -415,8 +355,10 @@ extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, fl
   hipStream_t st = (hipStream_t)stream;
   if (ctx_dim == 16) {
     if (wpack_floats != PackLayout<32, 32, 16, 128, 2, 8>::TOTAL) return VCNF_ERR_SHAPE;
-    return launch_fused<32, 32, 16, 128, 2, 8>(a, inverse, st);
+    if (precision == VCNF_PREC_F16X3) return launch_fused_v2_c16(a, inverse, st);
+    return launch_fused<32, 32, 16, 128, 2, 8, 2>(a, inverse, st);
   }
   if (wpack_floats != PackLayout<32, 32, 0, 128, 2, 8>::TOTAL) return VCNF_ERR_SHAPE;
-  return launch_fused<32, 32, 0, 128, 2, 8>(a, inverse, st);
+  if (precision == VCNF_PREC_F16X3) return launch_fused_v2_c0(a, inverse, st);
+  return launch_fused<32, 32, 0, 128, 2, 8, 2>(a, inverse, st);
 }

@@ -130,6 +130,9 @@ class PiecewiseRationalQuadraticCoupling(Flow):
         # use the single-kernel layer when shape and conditioner qualify (fused.eligible);
         # set False to force the three-step path (gather kernel, torch GEMMs, spline kernel)
         self.fused = True
+        # matrix path of the fused kernel: 'fp32' (exact fp32 fma chains) or 'fp16x3'
+        # (hi/lo split halves on the fp16 matrix cores, 22 significant bits, ~5x the rate)
+        self.fused_precision = None      # None: vcnf_amd.fused.DEFAULT_PRECISION
 
     @property
     def num_identity_features(self):

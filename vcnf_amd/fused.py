@@ -10,6 +10,8 @@ accumulators sit in registers.  Four consecutive k-steps are interleaved per lan
 that one 16-byte load feeds four matrix instructions.  The last layer's rows are
 permuted so that lane group q receives the 3K-1 logits of feature 4 g + q.
 """
+import os
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -65,15 +67,75 @@ def _pack_final(weight, bias, d_t, p):
     return wf.reshape(-1), bf.reshape(-1)
 
 
-def pack_layer(net, d_t, p):
-    """Flat fp32 buffer in the layout of csrc/fused_layer.hip::PackLayout."""
+PREC_F32, PREC_F16X3 = 0, 1
+LO_SCALE = 2048.0
+# matrix path used when a coupling does not set ``fused_precision`` itself
+DEFAULT_PRECISION = os.environ.get('VCNF_FUSED_PRECISION', 'fp32')
+
+
+def _split_halves(w):
+    """fp32 -> (hi, lo) fp16 with w ~= hi + lo / 2048 (22 significant bits)."""
+    hi = w.half()
+    lo = ((w - hi.float()) * LO_SCALE).half()
+    return hi, lo
+
+
+def _as_floats(h):
+    return h.contiguous().view(torch.float32).reshape(-1)
+
+
+def _pack_dense_h3(weight):
+    """Hidden->hidden layer for the fp16 matrix instruction (k-steps of 32): fragment
+    [nb][s][lane][8] holds W[16 nb + (lane & 15)][16 (2 s + (j >> 2)) + 4 (lane >> 4) + (j & 3)];
+    the hi halves of the whole layer come first, then the lo halves."""
+    n, k = weight.shape
+    dev = weight.device
+    nb = torch.arange(n // 16, device=dev).view(-1, 1, 1, 1)
+    s = torch.arange(k // 32, device=dev).view(1, -1, 1, 1)
+    lane = torch.arange(64, device=dev).view(1, 1, -1, 1)
+    j = torch.arange(8, device=dev).view(1, 1, 1, -1)
+    shape = (n // 16, k // 32, 64, 8)
+    rows = (16 * nb + (lane & 15)).expand(shape)
+    cols = (16 * (2 * s + (j >> 2)) + 4 * (lane >> 4) + (j & 3)).expand(shape)
+    hi, lo = _split_halves(weight[rows, cols])
+    return torch.cat([_as_floats(hi), _as_floats(lo)])
+
+
+def _pack_final_h3(weight, bias, d_t, p):
+    h = weight.shape[1]
+    p4 = (p + 3) // 4
+    dev = weight.device
+    g = torch.arange(d_t // 4, device=dev).view(-1, 1, 1, 1, 1)
+    b = torch.arange(p4, device=dev).view(1, -1, 1, 1, 1)
+    s = torch.arange(h // 32, device=dev).view(1, 1, -1, 1, 1)
+    lane = torch.arange(64, device=dev).view(1, 1, 1, -1, 1)
+    j = torch.arange(8, device=dev).view(1, 1, 1, 1, -1)
+    i = lane & 15
+    t = 4 * b + (i & 3)
+    shape = (d_t // 4, p4, h // 32, 64, 8)
+    rows = torch.where(t < p, (4 * g + (i >> 2)) * p + t, torch.zeros_like(t + g)).expand(shape)
+    cols = (16 * (2 * s + (j >> 2)) + 4 * (lane >> 4) + (j & 3)).expand(shape)
+    w = torch.where((t < p).expand(shape), weight[rows, cols], torch.zeros((), device=dev, dtype=weight.dtype))
+    hi, lo = _split_halves(w)
+    _, bf = _pack_final(weight, bias, d_t, p)
+    return torch.cat([_as_floats(hi), _as_floats(lo)]), bf
+
+
+def pack_layer(net, d_t, p, precision=PREC_F32):
+    """Flat fp32 buffer in the layout of csrc/fused_layer.hip::PackLayout.  With
+    PREC_F16X3 the hidden->hidden and last layers hold fp16 (hi | lo) fragments in the
+    same number of bytes; the first layer and the context gates stay fp32."""
+    dense = _pack_dense_h3 if precision == PREC_F16X3 else (lambda w: _pack_dense(w, True))
     parts = [_pack_dense(net.initial_layer.weight, False), net.initial_layer.bias]
     for blk in net.blocks:
-        parts += [_pack_dense(blk.linear_layers[0].weight, True), blk.linear_layers[0].bias,
-                  _pack_dense(blk.linear_layers[1].weight, True), blk.linear_layers[1].bias]
+        parts += [dense(blk.linear_layers[0].weight), blk.linear_layers[0].bias,
+                  dense(blk.linear_layers[1].weight), blk.linear_layers[1].bias]
         if net.context_features:
             parts += [_pack_dense(blk.context_layer.weight, False), blk.context_layer.bias]
-    wf, bf = _pack_final(net.final_layer.weight, net.final_layer.bias, d_t, p)
+    if precision == PREC_F16X3:
+        wf, bf = _pack_final_h3(net.final_layer.weight, net.final_layer.bias, d_t, p)
+    else:
+        wf, bf = _pack_final(net.final_layer.weight, net.final_layer.bias, d_t, p)
     parts += [wf, bf]
     return torch.cat([t.detach().reshape(-1).float() for t in parts]).contiguous()
 
@@ -103,14 +165,23 @@ def eligible(coupling, context):
         net.hidden_features, len(blocks), coupling.num_bins, _lib.TAILS_LINEAR))
 
 
+def precision_of(coupling):
+    mode = getattr(coupling, 'fused_precision', None) or DEFAULT_PRECISION
+    if mode not in ('fp32', 'fp16x3'):
+        raise ValueError("fused_precision must be 'fp32' or 'fp16x3'")
+    return PREC_F16X3 if mode == 'fp16x3' else PREC_F32
+
+
 def packed_weights(coupling):
-    """Cached packed buffer; rebuilt when any conditioner parameter changed."""
+    """Cached packed buffer; rebuilt when any conditioner parameter (or the matrix
+    precision) changed."""
     net = coupling.transform_net
-    key = tuple((p.data_ptr(), p._version) for p in net.parameters())
+    prec = precision_of(coupling)
+    key = (prec,) + tuple((p.data_ptr(), p._version) for p in net.parameters())
     cache = coupling.__dict__.get('_fused_pack')
     if cache is None or cache[0] != key:
         with torch.no_grad():
-            buf = pack_layer(net, coupling.num_transform_features, coupling._transform_dim_multiplier())
+            buf = pack_layer(net, coupling.num_transform_features, coupling._transform_dim_multiplier(), prec)
         cache = (key, buf)
         coupling.__dict__['_fused_pack'] = cache
     return cache[1]
@@ -121,5 +192,5 @@ def run(coupling, inputs, context, sampling, log_q=None, sign=1.0):
     shared = coupling.unconditional_transform.logits() if coupling.unconditional_transform is not None else None
     return _lib.rqs_layer_fused(inputs, context, coupling._index32('tf'), coupling._index32('id'),
                                 net.context_features or 0, net.hidden_features, len(net.blocks),
-                                packed_weights(coupling), shared, coupling._cfg(True), sampling,
+                                precision_of(coupling), packed_weights(coupling), shared, coupling._cfg(True), sampling,
                                 logdet=log_q, sign=sign)
