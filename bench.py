@@ -42,6 +42,7 @@ from vcnf_amd import _lib        # noqa: E402
 D, CTX, LAYERS, HIDDEN, BLOCKS, BINS, TAIL = 64, 16, 12, 128, 2, 8, 3.0
 HBM_PEAK = 8.0e12                                   # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK = 157.3e12                            # MI355X_MICROARCH.md: dense fp32 matrix peak
+MFMA_F16_PEAK = 2500.0e12                           # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
 P = 3 * BINS - 1
 BYTES_PER_SAMPLE_LAYER = 4 * D + 4 * (D // 2) * P + 4 * D + 8     # 3464, SURVEY 8(d)
 # conditioner flop per sample-layer (339 968): 2 * (48*128 + 4*128*128 + 2*16*128 + 128*736)
@@ -125,6 +126,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split", action="store_true",
                     help="three-step layers (gather kernel, torch GEMMs, spline kernel) instead of the fused kernel")
+    ap.add_argument("--precision", choices=["fp16x3", "fp32"], default="fp16x3",
+                    help="matrix path of the fused layer kernel: fp16 split-half (22-bit operands, fp32 "
+                         "accumulation; default) or exact fp32 matrix instructions")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,8 +145,11 @@ def main():
     nf.lib()
 
     model = build_model(device, seed=0)                      # replicated weights
-    for f in model.flows:
-        f.prqct.fused = not args.split
+    def route(split, precision):
+        for f in model.flows:
+            f.prqct.fused = not split
+            f.prqct.fused_precision = precision
+    route(args.split, args.precision)
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
     B = args.batch
     x = torch.randn(B, D, device=device, generator=gen)
@@ -190,10 +197,18 @@ def main():
     if args.split:
         work, peak, unit, bound, kname = BYTES_PER_SAMPLE_LAYER * B, HBM_PEAK, "GB/s", "hbm", "rqs_coupling_pf_kernel"
         note = "algorithmic bytes 3464 B/sample-layer (x + params + y + logdet)"
-    else:
+    elif args.precision == "fp32":
         work, peak, unit, bound, kname = FLOP_PER_SAMPLE_LAYER * B, MFMA_F32_PEAK, "TFLOP/s", "mfma", "fused_rqs_layer_kernel"
-        note = ("algorithmic flop %d per sample-layer (conditioner GEMMs); HBM side of the same launch: "
-                "%d B/sample-layer" % (FLOP_PER_SAMPLE_LAYER, 4 * D + 4 * CTX + 4 * D + 8))
+        note = ("algorithmic flop %d per sample-layer (conditioner GEMMs) on v_mfma_f32_16x16x4_f32; HBM side of "
+                "the same launch: %d B/sample-layer" % (FLOP_PER_SAMPLE_LAYER, 4 * D + 4 * CTX + 4 * D + 8))
+    else:
+        # split-half path: every product costs three f16 matrix instructions, so the ceiling for
+        # algorithmic flop is a third of the dense f16 peak
+        work, peak, unit, bound, kname = (FLOP_PER_SAMPLE_LAYER * B, MFMA_F16_PEAK / 3.0, "TFLOP/s", "mfma",
+                                          "fused_rqs_layer_v2_kernel")
+        note = ("algorithmic flop %d per sample-layer (conditioner GEMMs); peak = dense f16 matrix peak / 3 "
+                "(hi*hi + hi*lo + lo*hi per product, 22-bit operands, fp32 accumulation); HBM side of the same "
+                "launch: %d B/sample-layer" % (FLOP_PER_SAMPLE_LAYER, 4 * D + 4 * CTX + 4 * D + 8))
     achieved = work / kern_s if durs else 0.0
     scale = 1e9 if unit == "GB/s" else 1e12
     traffic = pmc_traffic(kname, B)
@@ -222,6 +237,23 @@ def main():
                     "unit": "GB/s", "frac": round(BYTES_PER_SAMPLE_LAYER * B / t_sp / HBM_PEAK, 4),
                     "avg_launch_ms": round(t_sp * 1e3, 4)}
 
+    # the other matrix path of the fused kernel, same workload, outside the timed region
+    other = None
+    if rank == 0 and world == 1 and not args.split:
+        alt = "fp32" if args.precision == "fp16x3" else "fp16x3"
+        route(False, alt)
+        with torch.no_grad():
+            step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            dt_alt = (time.perf_counter() - t1) / 2
+        route(args.split, args.precision)
+        other = {"matrix_path": alt, "value": round(2.0 * B / dt_alt, 1), "unit": "transforms/s",
+                 "ms_per_step": round(1e3 * dt_alt, 3)}
+
     if rank == 0:
         transforms = 2.0 * B * args.steps * world
         out = {
@@ -244,6 +276,9 @@ def main():
         }
         if hbm_side is not None:
             out["roofline_hbm_spline_kernel"] = hbm_side
+        if other is not None:
+            out["other_matrix_path"] = other
+        out["config"]["matrix_path"] = "split (torch GEMMs)" if args.split else args.precision
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(out))

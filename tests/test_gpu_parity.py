@@ -38,15 +38,17 @@ def load(module, sd, fused=True):
 
 
 def set_fused(module, flag):
-    """Route eligible RQS couplings through the single-kernel layer (True) or through
-    the gather kernel + torch GEMMs + spline kernel (False)."""
+    """Route eligible RQS couplings through the single-kernel layer - "fp16x3" (split-half
+    fp16 matrix path, the default) or "fp32" (exact fp32 matrix path) - or, with False,
+    through the gather kernel + torch GEMMs + spline kernel."""
     for m in module.modules():
         if isinstance(m, nf.flows.PiecewiseRationalQuadraticCoupling):
-            m.fused = flag
+            m.fused = bool(flag)
+            m.fused_precision = flag if isinstance(flag, str) else None
     return module
 
 
-FUSED = pytest.mark.parametrize("fused", [True, False], ids=["fused", "split"])
+FUSED = pytest.mark.parametrize("fused", ["fp16x3", "fp32", False], ids=["fused-fp16x3", "fused-fp32", "split"])
 
 
 # ---------------------------------------------------------------- splines (G1, G2)
@@ -603,14 +605,15 @@ def test_fused_path_is_taken_and_matches_split_path(hip):
         assert fz.eligible(m.prqct, ctx)
         with torch.no_grad():
             for dirn in ("inverse", "forward"):
-                m.prqct.fused = True
-                zf, lf = getattr(m, dirn)(x, context=ctx)
-                m.prqct.fused = False
+                set_fused(m, False)
                 zs, ls = getattr(m, dirn)(x, context=ctx)
-                assert_close(zf, zs.cpu(), rtol=1e-4, atol=1e-4, what="%s z" % dirn)
-                assert_close(lf, ls.cpu(), rtol=1e-4, atol=2e-3, what="%s ld" % dirn)
+                for prec in ("fp32", "fp16x3"):
+                    set_fused(m, prec)
+                    zf, lf = getattr(m, dirn)(x, context=ctx)
+                    assert_close(zf, zs.cpu(), rtol=1e-4, atol=1e-4, what="%s %s z" % (prec, dirn))
+                    assert_close(lf, ls.cpu(), rtol=1e-4, atol=2e-3, what="%s %s ld" % (prec, dirn))
         # weights changed in place -> the packed copy is rebuilt
-        m.prqct.fused = True
+        set_fused(m, "fp16x3")
         with torch.no_grad():
             z0, _ = m.inverse(x, context=ctx)
             m.prqct.transform_net.final_layer.bias.add_(0.3)
@@ -619,3 +622,15 @@ def test_fused_path_is_taken_and_matches_split_path(hip):
     # shapes outside the kernel's family fall back to the split path
     other = nf.flows.CoupledRationalQuadraticSpline(20, 2, 64, 8).cuda().eval()
     assert not fz.eligible(other.prqct, None)
+
+
+def test_fp16x3_saturates_instead_of_nan(hip):
+    """Hidden activations beyond the fp16 range saturate at +-65504 in the split-half
+    matrix path: outputs stay finite (they differ from the fp32 path there, documented)."""
+    torch.manual_seed(22)
+    m = set_fused(nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8).cuda().eval(), "fp16x3")
+    x = torch.randn(256, 64, device="cuda")
+    x[::7, ::2] *= 3e6          # absurd identity features -> huge hidden activations
+    with torch.no_grad():
+        z, ld = m.inverse(x)
+    assert torch.isfinite(z).all() and torch.isfinite(ld).all()

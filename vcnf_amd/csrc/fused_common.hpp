@@ -26,7 +26,6 @@ struct FusedArgs {
   long long B;
   int ld_mode;
   float ld_sign;
-  int dbg;                               // scratch experiments only (VCNF_DBG env)
   RqsConst c;
 };
 

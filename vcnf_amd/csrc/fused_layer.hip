@@ -342,7 +342,6 @@ extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, fl
   a.sh_w = shared_w; a.sh_h = shared_h; a.sh_d = shared_d;
   a.wpack = wpack; a.wpack_bytes = (unsigned)(wpack_floats * 4);
   a.bad = bad_disc; a.B = batch; a.ld_mode = ld_mode; a.ld_sign = ld_sign;
-  { const char* e = getenv("VCNF_DBG"); a.dbg = e ? atoi(e) : 0; }
   const int K = cfg->num_bins;
   a.c.K = K; a.c.tails = cfg->tails;
   a.c.lo_x = cfg->left; a.c.hi_x = cfg->right; a.c.span_x = (float)((double)cfg->right - (double)cfg->left);

@@ -46,8 +46,8 @@ template <bool RELU>
 __device__ __forceinline__ void split4(const floatx4 v, half4& hi, half4& lo) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    float x = v[r];
-    if (RELU) x = fmaxf(x, 0.f);
+    // ReLU and saturation at the fp16 range in one v_med3_f32 (no inf after the conversion)
+    const float x = __builtin_amdgcn_fmed3f(v[r], RELU ? 0.f : -65504.f, 65504.f);
     const _Float16 hv = (_Float16)x;
     hi[r] = hv;
     lo[r] = (_Float16)((x - (float)hv) * kLoScale);
@@ -146,21 +146,23 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_rqs_layer_v2_kernel(const Fu
     }
     __syncthreads();
 
-    // ---- identity half through the unconditional spline (32 lanes per sample, DI <= 32:
-    // one feature per lane); per-sample log|det| of this half parked in LDS.
+    // ---- identity half through the unconditional spline: 4 lanes per sample, each lane a run
+    // of DI/4 features; per-sample log|det| of this half parked in LDS.
 #define VCNF_IDENTITY_PASS()                                                              \
-  for (int e = tid; e < kV2Tile * 32; e += kV2Block) {                                    \
-    const int mi = e >> 5, f = e & 31;                                                    \
-    float lad = 0.f;                                                                      \
-    if (f < DI) {                                                                         \
+  for (int mi = tid >> 2; mi < kV2Tile; mi += kV2Block / 4) {                             \
+    float lsum = 0.f;                                                                     \
+    _Pragma("unroll") for (int k = 0; k < DI / 4; ++k) {                                  \
+      const int f = (tid & 3) * (DI / 4) + k;                                             \
       float* px = xt + mi * XS + idi[f];                                                  \
       const float xv = *px;                                                               \
-      float yv = xv;                                                                      \
-      if (shared) rqs_point_table<INV>(xv, tab + f * TABW, c, yv, lad, bad);              \
+      float yv = xv, lad = 0.f;                                                           \
+      if (shared) rqs_point_table<INV, K>(xv, tab + f * TABW, c, yv, lad, bad);           \
       *px = yv;                                                                           \
+      lsum += lad;                                                                        \
     }                                                                                     \
-    for (int sh = 16; sh > 0; sh >>= 1) lad += __shfl_xor(lad, sh, 64);                   \
-    if (f == 0) ldt[mi] = lad;                                                            \
+    lsum += __shfl_xor(lsum, 1, 64);                                                      \
+    lsum += __shfl_xor(lsum, 2, 64);                                                      \
+    if ((tid & 3) == 0) ldt[mi] = lsum;                                                   \
   }
     if (INV) {
       VCNF_IDENTITY_PASS()
@@ -178,22 +180,41 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_rqs_layer_v2_kernel(const Fu
         for (int s4 = 0; s4 < NS0_4; ++s4) w0[rb][s4] = wload(wr, voff, 4 * (L::W0 + (nb * NS0_4 + s4) * 256));
         bias[rb] = wload(wr, qoff, 4 * (L::B0 + 16 * nb));
       }
+      // operand columns of this lane: identity feature 4 s + q (read once, not per use)
+      int xcol[DI / 4];
+#pragma unroll
+      for (int s = 0; s < DI / 4; ++s) xcol[s] = idi[4 * s + q];
+      float bv[kV2CB][NS0];
 #pragma unroll
       for (int cb = 0; cb < kV2CB; ++cb) {
         const float* xr = xt + (cb * 16 + m16) * XS;
         const float* cr = ct + (cb * 16 + m16) * CS;
+#pragma unroll
+        for (int s = 0; s < NS0; ++s) bv[cb][s] = s < DI / 4 ? xr[xcol[s]] : cr[4 * (s - DI / 4) + q];
+      }
+#pragma unroll
+      for (int cb = 0; cb < kV2CB; ++cb) {
         floatx4 acc[RBW];
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb) acc[rb] = bias[rb];
 #pragma unroll
         for (int s = 0; s < NS0; ++s) {
-          const float bv = s < DI / 4 ? xr[idi[4 * s + q]] : cr[4 * (s - DI / 4) + q];
 #pragma unroll
-          for (int rb = 0; rb < RBW; ++rb) acc[rb] = mfma4(w0[rb][s >> 2][s & 3], bv, acc[rb]);
+          for (int rb = 0; rb < RBW; ++rb) acc[rb] = mfma4(w0[rb][s >> 2][s & 3], bv[cb][s], acc[rb]);
         }
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb) h[rb][cb] = acc[rb];
       }
+      // schedule: a column block's operand reads run one block ahead of its matrix work
+      // (left alone the scheduler puts every LDS read right before the MFMA that uses it
+      // and each MFMA then waits out a full LDS round trip)
+      __builtin_amdgcn_sched_group_barrier(0x100, NS0, 0);
+#pragma unroll
+      for (int cb = 0; cb + 1 < kV2CB; ++cb) {
+        __builtin_amdgcn_sched_group_barrier(0x100, NS0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NS0 * RBW, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NS0 * RBW, 0);
     }
     if (!INV) {
       __syncthreads();
@@ -250,7 +271,7 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_rqs_layer_v2_kernel(const Fu
   }
 
 #pragma unroll
-    for (int blk = 0; blk < ((a.dbg & 4) ? 0 : NBLK); ++blk) {
+    for (int blk = 0; blk < NBLK; ++blk) {
       const int base = L::BLK0 + blk * L::BLK;
       floatx4 t[RBW][kV2CB];
       VCNF_HIDDEN_LAYER(base + L::WA, base + L::BA, t)                                  // resnet.py:42-43
@@ -303,9 +324,9 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_rqs_layer_v2_kernel(const Fu
     }
     float ld_acc = 0.f;
     const int mrow = wave * 16 + m16;
-    for (int g = 0; g < ((a.dbg & 8) ? 1 : NG); ++g) {
+    for (int g = 0; g < NG; ++g) {
       __syncthreads();                       // window free (operands read / previous group consumed)
-      if (!((a.dbg & 1) && g > 0)) {   // stage the group's weights: [b][s][hi|lo][lane] 16-byte fragments, 48 KB
+      {   // stage the group's weights: [b][s][hi|lo][lane] 16-byte fragments, 48 KB
         constexpr int NFRAG = P4 * NS32 * 2 * 64;
         for (int i = tid; i < NFRAG; i += kV2Block) {
           const int ln = i & 63, part = (i >> 6) & 1, bs = i >> 7;     // bs = b * NS32 + s
@@ -333,8 +354,8 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_rqs_layer_v2_kernel(const Fu
       const float xv = *px;
       RegLogits<K, P4> p{pa, c.wh_scale, c.edge_logit};
       float yv, lad;
-      if ((c.tails == 1 && !((xv >= c.lo_x) && (xv <= c.hi_x))) || (a.dbg & 2)) {
-        yv = xv + ((a.dbg & 2) ? pa[0][0] + pa[5][2] : 0.f);
+      if (c.tails == 1 && !((xv >= c.lo_x) && (xv <= c.hi_x))) {
+        yv = xv;
         lad = 0.f;
       } else {
         RqsBin sel;
@@ -396,13 +417,11 @@ static int launch_v2(const FusedArgs& a, int inverse, hipStream_t st) {
 }
 
 int launch_fused_v2_c16(const FusedArgs& a, int inverse, hipStream_t st) {
-  if (a.dbg & 16) return launch_v2<32, 32, 16, 128, 2, 8, 8>(a, inverse, st);
-  return launch_v2<32, 32, 16, 128, 2, 8, 4>(a, inverse, st);
+  return launch_v2<32, 32, 16, 128, 2, 8, 8>(a, inverse, st);
 }
 
 int launch_fused_v2_c0(const FusedArgs& a, int inverse, hipStream_t st) {
-  if (a.dbg & 16) return launch_v2<32, 32, 0, 128, 2, 8, 8>(a, inverse, st);
-  return launch_v2<32, 32, 0, 128, 2, 8, 4>(a, inverse, st);
+  return launch_v2<32, 32, 0, 128, 2, 8, 8>(a, inverse, st);
 }
 
 }  // namespace vcnf

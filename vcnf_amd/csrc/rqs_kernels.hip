@@ -43,7 +43,6 @@ struct CouplingArgs {
   int JC;         // transformed features per params chunk (== d_t: whole rows)
   int vec_x;      // x / y tiles may use 16-byte accesses
   int vec_p;      // params chunks may use 16-byte accesses
-  int dbg;        // scratch experiments only (VCNF_DBG env): 1 = skip the spline arithmetic
   int sh_mode;    // shared (unconditional) spline: 0 absent, 1 knot tables in LDS, 2 logits read from HBM/L2
   int ld_mode;
   float ld_sign;
@@ -265,8 +264,7 @@ __global__ __launch_bounds__(kBlock) void rqs_coupling_pf_kernel(const CouplingA
         const float xv = xt[s * a.D + col];
         PackedLogits p{pt + s * seg + j * a.P, K, c.wh_scale, c.edge_logit, c.tails};
         float yv, lad;
-        if (a.dbg == 1) { yv = xv + p.q[0] * 0.f; lad = p.q[22]; }
-        else rqs_point<KT, INV>(xv, p, c, yv, lad, bad);
+        rqs_point<KT, INV>(xv, p, c, yv, lad, bad);
         yt[s * a.D + col] = yv;
         acc += lad;
       }
@@ -274,8 +272,7 @@ __global__ __launch_bounds__(kBlock) void rqs_coupling_pf_kernel(const CouplingA
         const int col = idi[j];
         const float xv = xt[s * a.D + col];
         float yv = xv, lad = 0.f;
-        if (a.dbg == 1) {
-        } else if (a.sh_mode == 1) {
+        if (a.sh_mode == 1) {
           rqs_point_table<INV>(xv, tab + j * tabw, c, yv, lad, bad);
         } else if (a.sh_mode == 2) {
           SplitLogits p{a.sh_w + (long long)j * K, a.sh_h + (long long)j * K, a.sh_d + (long long)j * a.Pd,
@@ -514,7 +511,6 @@ extern "C" int vcnf_rqs_coupling_f32(const float* x, const float* params,
   a.G = pick_group(d_t, d_id, a.P, K, a.sh_mode);
   a.S = kBlock / a.G;
   a.ld_mode = ld_mode; a.ld_sign = ld_sign;
-  { const char* e = getenv("VCNF_DBG"); a.dbg = e ? atoi(e) : 0; }
 
   // LDS plan: x tile + y tile + tables + indices are fixed; the params chunk takes the rest.
   const size_t fixed = fixed_lds(a.S, D, d_id, K, a.sh_mode);

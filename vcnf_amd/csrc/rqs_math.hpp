@@ -228,7 +228,8 @@ __device__ __forceinline__ void rqs_build_table(const P& p, const RqsConst& c, f
   }
 }
 
-template <bool INV>
+// KT > 0: bin count known at compile time (the knot scan unrolls and its LDS reads batch).
+template <bool INV, int KT = 0>
 __device__ __forceinline__ void rqs_point_table(float x, const float* tab, const RqsConst& c,
                                                 float& y, float& lad, bool& bad) {
   if (c.tails == 1 && !((x >= c.lo_x) && (x <= c.hi_x))) {
@@ -236,13 +237,18 @@ __device__ __forceinline__ void rqs_point_table(float x, const float* tab, const
     lad = 0.f;
     return;
   }
-  const int K = c.K;
+  const int K = KT > 0 ? KT : c.K;
   const float* xk = tab;
   const float* yk = tab + (K + 1);
   const float* dk = tab + 2 * (K + 1);
   int bin = 0;
   const float* key = INV ? yk : xk;
-  for (int k = 1; k < K; ++k) bin += (x >= key[k]) ? 1 : 0;   // knots ascend: count = last hit
+  if (KT > 0) {
+#pragma unroll
+    for (int k = 1; k < KT; ++k) bin += (x >= key[k]) ? 1 : 0;   // knots ascend: count = last hit
+  } else {
+    for (int k = 1; k < K; ++k) bin += (x >= key[k]) ? 1 : 0;
+  }
   RqsBin b;
   b.xl = xk[bin];
   b.w = xk[bin + 1] - b.xl;

@@ -70,7 +70,7 @@ def _pack_final(weight, bias, d_t, p):
 PREC_F32, PREC_F16X3 = 0, 1
 LO_SCALE = 2048.0
 # matrix path used when a coupling does not set ``fused_precision`` itself
-DEFAULT_PRECISION = os.environ.get('VCNF_FUSED_PRECISION', 'fp32')
+DEFAULT_PRECISION = os.environ.get('VCNF_FUSED_PRECISION', 'fp16x3')
 
 
 def _split_halves(w):
