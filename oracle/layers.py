@@ -323,3 +323,98 @@ class Stack:
             if trace is not None:
                 trace.append((z, ld))
         return z, log_q
+
+
+class Invertible1x1ConvLU:
+    """flows/mixing.py:57-128 with use_lu=True: W = P (tril(L,-1)+I) (triu(U,1)+diag(sign_S e^{log_S}))."""
+
+    def __init__(self, P, L, U, sign_S, log_S, eye):
+        self.P, self.L, self.U, self.sign_S, self.log_S, self.eye = P, L, U, sign_S, log_S, eye
+        self.c = P.shape[0]
+
+    def _w(self, inverse):
+        lo = torch.tril(self.L, diagonal=-1) + self.eye                       # :85
+        up = torch.triu(self.U, diagonal=1) + torch.diag(self.sign_S * torch.exp(self.log_S))
+        if inverse:                                                           # :87-95
+            li = torch.inverse(lo.double()).type(self.log_S.dtype)
+            ui = torch.inverse(up.double()).type(self.log_S.dtype)
+            return ui @ li @ self.P.t()
+        return self.P @ lo @ up                                               # :97
+
+    def forward(self, z):                                                     # :100-116
+        w = self._w(True).view(self.c, self.c, 1, 1)
+        return torch.nn.functional.conv2d(z, w), -torch.sum(self.log_S) * z.size(2) * z.size(3)
+
+    def inverse(self, z):                                                     # :118-128
+        w = self._w(False).view(self.c, self.c, 1, 1)
+        return torch.nn.functional.conv2d(z, w), torch.sum(self.log_S) * z.size(2) * z.size(3)
+
+
+class Squeeze:
+    """flows/reshape.py:93-116."""
+
+    def forward(self, z):
+        s = z.size()
+        z = z.view(s[0], s[1] // 4, 2, 2, s[2], s[3]).permute(0, 1, 4, 2, 5, 3).contiguous()
+        return z.view(s[0], s[1] // 4, 2 * s[2], 2 * s[3]), 0
+
+    def inverse(self, z):
+        s = z.size()
+        z = z.view(*s[:2], s[2] // 2, 2, s[3] // 2, 2).permute(0, 1, 3, 5, 2, 4).contiguous()
+        return z.view(s[0], 4 * s[1], s[2] // 2, s[3] // 2), 0
+
+
+class Chain:
+    """GlowBlock-style composite (flows/affine/glow.py:63-74): flows in order, log-dets summed."""
+
+    def __init__(self, flows):
+        self.flows = list(flows)
+
+    def forward(self, z):
+        tot = torch.zeros(z.shape[0], dtype=z.dtype)
+        for f in self.flows:
+            z, ld = f.forward(z)
+            tot = tot + ld
+        return z, tot
+
+    def inverse(self, z):
+        tot = torch.zeros(z.shape[0], dtype=z.dtype)
+        for f in reversed(self.flows):
+            z, ld = f.inverse(z)
+            tot = tot + ld
+        return z, tot
+
+
+class Multiscale:
+    """core.py MultiscaleFlow: log_prob :348-367, sample :320-340 (channel Merge between
+    levels: reshape.py:50-55, :25-29)."""
+
+    def __init__(self, q0, flows):
+        self.q0, self.flows = list(q0), [list(f) for f in flows]
+
+    def log_prob(self, x):
+        log_q, z = 0, x
+        for i in range(len(self.q0) - 1, -1, -1):
+            for f in reversed(self.flows[i]):
+                z, ld = f.inverse(z)
+                log_q = log_q + ld
+            if i > 0:
+                z, z_ = z.chunk(2, dim=1)           # Merge.inverse = Split.forward, mode 'channel'
+            else:
+                z_ = z
+            log_q = log_q + self.q0[i].log_prob(z_)
+        return log_q
+
+    def sample_from(self, noise):
+        z = log_q = None
+        for i in range(len(self.q0)):
+            z_, lq_ = self.q0[i].from_noise(noise[i])
+            if i == 0:
+                z, log_q = z_, lq_
+            else:
+                log_q = log_q + lq_
+                z = torch.cat([z, z_], 1)           # Merge.forward
+            for f in self.flows[i]:
+                z, ld = f.forward(z)
+                log_q = log_q - ld
+        return z, log_q

@@ -44,3 +44,17 @@ def mlp(sd, prefix, x, leaky=0.0):
         if n + 1 < len(idx):
             h = F.leaky_relu(h, leaky)
     return h
+
+
+def conv_net(sd, prefix, x, leaky=0.0):
+    """nets/cnn.py:27-46 without actnorm: Conv2d ('same' padding), LeakyReLU, ..., Conv2d;
+    convolutions sit at even positions of ``net``."""
+    idx = sorted({int(k[len(prefix) + 4:].split(".")[0]) for k in sd
+                  if k.startswith(prefix + "net.") and k.endswith(".weight")})
+    h = x
+    for n, i in enumerate(idx):
+        w, b = sd[prefix + "net.%d.weight" % i], sd[prefix + "net.%d.bias" % i]
+        h = F.conv2d(h, w, b, padding=w.shape[-1] // 2)
+        if n + 1 < len(idx):
+            h = F.leaky_relu(h, leaky)
+    return h

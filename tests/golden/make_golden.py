@@ -423,6 +423,97 @@ def g12_c2_tabular():
     save("g12_c2_tabular", **out)
 
 
+# ---------------------------------------------------------------- G11 tiny Glow multiscale (C4 family)
+def g11_glow_multiscale():
+    out = {}
+    L, K, hidden = 2, 2, 16
+    input_shape = (3, 8, 8)
+    r = rng(1100)
+    x = torch.from_numpy(r.random((16,) + input_shape, dtype=np.float32))
+    shapes = []
+    for i in range(L):
+        if i > 0:
+            shapes.append((input_shape[0] * 2 ** (L - i), input_shape[1] // 2 ** (L - i), input_shape[2] // 2 ** (L - i)))
+        else:
+            shapes.append((input_shape[0] * 2 ** (L + 1), input_shape[1] // 2 ** L, input_shape[2] // 2 ** L))
+    noise = [torch.from_numpy(r.standard_normal((16,) + sh).astype(np.float32)) for sh in shapes]
+    fixed = ("P", "sign_S", "eye", "data_dep_init_done")
+
+    def build():
+        torch.manual_seed(5)
+        q0, merges, flows = [], [], []
+        for i in range(L):
+            fl = [nf.flows.GlowBlock(input_shape[0] * 2 ** (L + 1 - i), hidden, split_mode="channel", scale=True)
+                  for _ in range(K)]
+            fl += [nf.flows.Squeeze()]
+            flows += [fl]
+            if i > 0:
+                merges += [nf.flows.Merge()]
+            q0 += [nf.distributions.DiagGaussian(shapes[i])]
+        m = nf.MultiscaleFlow(q0, flows, merges, class_cond=False)
+        for name, buf in m.named_buffers():
+            if name.endswith("data_dep_init_done"):
+                buf.fill_(1.0)                       # no data-dependent initialisation in the fixture
+        return m
+
+    def call(m, a, *eps):
+        lp = m.log_prob(a, None)
+        # MultiscaleFlow.sample (core.py:320-340) with the base draws supplied
+        z = log_q = None
+        for i in range(L):
+            q = m.q0[i]
+            z_ = q.loc + torch.exp(q.log_scale) * eps[i]
+            lq_ = -0.5 * q.d * np.log(2 * np.pi) - torch.sum(q.log_scale + 0.5 * torch.pow(eps[i], 2), [1, 2, 3])
+            if i == 0:
+                z, log_q = z_, lq_
+            else:
+                log_q = log_q + lq_
+                z, ld = m.merges[i - 1]([z, z_])
+                log_q = log_q - ld
+            for f in m.flows[i]:
+                z, ld = f(z)
+                log_q = log_q - ld
+        return (lp, z, log_q)
+    m0 = build()
+    skip = tuple(k for k in m0.state_dict() if k.split(".")[-1] in fixed)
+    ents, ints, o32, o64, mref = run_module_case(build, 1101, [x] + noise, call, skip=skip, weight_gain=0.5)
+    pack(out, "glow", ents, ints, ["lp", "s_z", "s_logq"], o32, o64)
+    for k in skip:
+        out["glow/buf/" + k] = npy(mref.state_dict()[k])
+    out["x"] = npy(x)
+    for i, e in enumerate(noise):
+        out["eps%d" % i] = npy(e)
+    save("g11_glow_multiscale", **out)
+
+
+# ---------------------------------------------------------------- C5 layer shape (D=1024, K=16), 2 layers
+def g13_c5_shape():
+    out = {}
+    r = rng(1300)
+    x = torch.from_numpy(r.standard_normal((64, 1024)).astype(np.float32))
+    eps = torch.from_numpy(r.standard_normal((64, 1024)).astype(np.float32))
+
+    def build():
+        flows = [nf.flows.CoupledRationalQuadraticSpline(1024, 2, 128, 16, reverse_mask=bool(i % 2))
+                 for i in range(2)]
+        m = nf.NormalizingFlow(nf.distributions.DiagGaussian(1024), flows)
+        m.categoricals = None
+        return m
+
+    def call(m, a, e):
+        lp = m.log_prob(a.clone())
+        z = m.q0.loc + torch.exp(m.q0.log_scale) * e
+        log_q = -0.5 * m.q0.d * np.log(2 * np.pi) - torch.sum(m.q0.log_scale + 0.5 * torch.pow(e, 2), 1)
+        for f in m.flows:
+            z, ld = f(z)
+            log_q -= ld
+        return (lp, z, log_q)
+    ents, ints, o32, o64, _ = run_module_case(build, 1301, [x, eps], call, final_gain=1.0)
+    pack(out, "c5", ents, ints, ["lp", "s_z", "s_logq"], o32, o64)
+    out["x"], out["eps"] = npy(x), npy(eps)
+    save("g13_c5_shape", **out)
+
+
 if __name__ == "__main__":
     g1_rqs()
     g2_tails()
@@ -434,4 +525,6 @@ if __name__ == "__main__":
     g8_indices()
     g9_diag_gaussian()
     g10_c1_two_moons()
+    g11_glow_multiscale()
     g12_c2_tabular()
+    g13_c5_shape()

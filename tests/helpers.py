@@ -53,6 +53,12 @@ def oracle_c3_stack(sd, layers=12, num_bins=8, tail_bound=3.0, hidden=128):
     return OL.Stack(OL.DiagGaussian(sd["q0.loc"], sd["q0.log_scale"]), flows)
 
 
+def oracle_crqs_stack(sd, layers, num_bins, tail_bound, hidden):
+    """CoupledRationalQuadraticSpline x layers + DiagGaussian (no context)."""
+    flows = [oracle_rqs_coupling(sd, "flows.%d.prqct." % i, num_bins, tail_bound, hidden) for i in range(layers)]
+    return OL.Stack(OL.DiagGaussian(sd["q0.loc"], sd["q0.log_scale"]), flows)
+
+
 def oracle_affine_stack(sd, layers, d, leaky=0.0):
     """[AffineCouplingBlock(MLP), Permute(d,'swap')] x layers + DiagGaussian."""
     flows = []
@@ -61,6 +67,33 @@ def oracle_affine_stack(sd, layers, d, leaky=0.0):
         flows.append(OL.AffineCouplingBlock(lambda z, pm=pm: ON.mlp(sd, pm, z, leaky)))
         flows.append(OL.Permute(d, "swap"))
     return OL.Stack(OL.DiagGaussian(sd["q0.loc"], sd["q0.log_scale"]), flows)
+
+
+def oracle_glow_multiscale(sd, levels=2, blocks=2):
+    """Tiny Glow of fixture G11: per level `blocks` GlowBlocks + Squeeze, DiagGaussian bases."""
+    q0, flows = [], []
+    for i in range(levels):
+        fl = []
+        for j in range(blocks):
+            pre = "flows.%d.%d." % (i, j)
+            pm = pre + "flows.0.flows.1.param_map."
+            coupling = OL.AffineCouplingBlock(lambda z, pm=pm: ON.conv_net(sd, pm, z), scale_map="sigmoid")
+            conv = OL.Invertible1x1ConvLU(*(sd[pre + "flows.1." + n] for n in ("P", "L", "U", "sign_S", "log_S", "eye")))
+            act = OL.AffineConst(sd[pre + "flows.2.s"], sd[pre + "flows.2.t"])
+            fl.append(OL.Chain([coupling, conv, act]))
+        fl.append(OL.Squeeze())
+        flows.append(fl)
+        q0.append(OL.DiagGaussian(sd["q0.%d.loc" % i], sd["q0.%d.log_scale" % i]))
+    return OL.Multiscale(q0, flows)
+
+
+def glow_state(fx, seed, dtype=torch.float32):
+    """State dict of fixture G11: synthetic weights (gain 0.5) + the reference's fixed buffers."""
+    sd, _ = state_for(fx, "glow", seed, dtype, weight_gain=0.5)
+    for k, v in fx.items():
+        if k.startswith("glow/buf/"):
+            sd[k[len("glow/buf/"):]] = T(v, dtype)
+    return sd
 
 
 def assert_close(got, want, rtol, atol, what=""):

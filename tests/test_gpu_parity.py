@@ -19,7 +19,7 @@ import torch
 import vcnf_amd as nf
 from vcnf_amd import _lib
 from helpers import (fixture, T, state_for, assert_close, within_reference_noise, parity,
-                     oracle_rqs_coupling, oracle_c3_stack, oracle_affine_stack)
+                     oracle_rqs_coupling, oracle_c3_stack, oracle_affine_stack, glow_state)
 from oracle import rqs as OR, layers as OL, nets as ON
 
 pytestmark = pytest.mark.gpu
@@ -634,3 +634,71 @@ def test_fp16x3_saturates_instead_of_nan(hip):
     with torch.no_grad():
         z, ld = m.inverse(x)
     assert torch.isfinite(z).all() and torch.isfinite(ld).all()
+
+
+def test_g13_c5_layer_shape(hip):
+    """Config C5's layer shape against the reference: D=1024, K=16 (P=47), conditioner
+    512 -> 24064; the spline kernel streams each sample's 96 KB of params in feature chunks
+    and the unconditional spline reads its logits from L2 instead of LDS tables."""
+    fx = fixture("g13_c5_shape")
+    sd, _ = state_for(fx, "c5", 1301, final_gain=1.0)
+    flows = [nf.flows.CoupledRationalQuadraticSpline(1024, 2, 128, 16, reverse_mask=bool(i % 2)) for i in range(2)]
+    model = load(nf.NormalizingFlow(nf.distributions.DiagGaussian(1024), flows), sd)
+    with torch.no_grad():
+        lp = model.log_prob(dev(T(fx["x"])))
+        assert_close(lp, fx["c5/lp32"], what="log_prob (1e-5 rel)", **LP)
+        parity(lp, fx["c5/lp32"], fx["c5/lp64"], rtol=1e-5, atol=2e-4, what="log_prob")
+        z, lq = model.sample_from(dev(T(fx["eps"])))
+        parity(z, fx["c5/s_z32"], fx["c5/s_z64"], what="sample z")
+        parity(lq, fx["c5/s_logq32"], fx["c5/s_logq64"], rtol=1e-5, atol=2e-4, what="sample log_q")
+    nf.check_discriminant()
+
+
+def _glow_model(levels=2, blocks=2, hidden=16, input_shape=(3, 8, 8)):
+    q0, merges, flows, L = [], [], [], levels
+    for i in range(L):
+        fl = [nf.flows.GlowBlock(input_shape[0] * 2 ** (L + 1 - i), hidden, split_mode="channel", scale=True)
+              for _ in range(blocks)]
+        fl += [nf.flows.Squeeze()]
+        flows += [fl]
+        if i > 0:
+            merges += [nf.flows.Merge()]
+            shape = (input_shape[0] * 2 ** (L - i), input_shape[1] // 2 ** (L - i), input_shape[2] // 2 ** (L - i))
+        else:
+            shape = (input_shape[0] * 2 ** (L + 1), input_shape[1] // 2 ** L, input_shape[2] // 2 ** L)
+        q0 += [nf.distributions.DiagGaussian(shape)]
+    return nf.MultiscaleFlow(q0, flows, merges, class_cond=False)
+
+
+def test_g11_glow_multiscale(hip):
+    """Config C4's family end to end against the reference: MultiscaleFlow.log_prob / sample
+    through GlowBlocks whose affine coupling (4-D, sigmoid scale map, conv conditioner) and
+    ActNorm run on the HIP kernels; 1x1 convolution and conditioner convs on PyTorch-ROCm."""
+    fx = fixture("g11_glow_multiscale")
+    model = load(_glow_model(), glow_state(fx, 1101))
+    with torch.no_grad():
+        lp = model.log_prob(dev(T(fx["x"])))
+        parity(lp, fx["glow/lp32"], fx["glow/lp64"], rtol=1e-5, atol=1e-3, what="log_prob")
+        z, lq = model.sample_from([dev(T(fx["eps0"])), dev(T(fx["eps1"]))])
+        parity(z, fx["glow/s_z32"], fx["glow/s_z64"], rtol=1e-4, atol=1e-4, what="sample z")
+        parity(lq, fx["glow/s_logq32"], fx["glow/s_logq64"], rtol=1e-5, atol=1e-3, what="sample log_q")
+        z2, lq2 = model.sample(5)
+        assert z2.shape == (5, 3, 8, 8) and lq2.shape == (5,)
+
+
+def test_actnorm_data_dependent_init(hip):
+    """First batch standardises the output (normalization.py:20-27), then parameters stay."""
+    torch.manual_seed(31)
+    a = nf.flows.ActNorm((6, 1, 1)).cuda()
+    x = 3.0 * torch.randn(64, 6, 5, 5, device="cuda") + 2.0
+    with torch.no_grad():
+        y, ld = a(x)
+        assert float(a.data_dep_init_done) == 1.0
+        assert_close(y.mean(dim=(0, 2, 3)), torch.zeros(6), rtol=0, atol=1e-4, what="mean")
+        assert_close(y.std(dim=(0, 2, 3)), torch.ones(6), rtol=0, atol=1e-3, what="std")
+        s0 = a.s.clone()
+        a(x + 1.0)
+        assert torch.equal(a.s, s0)
+        xr, ldi = a.inverse(y)
+        assert_close(xr, x.cpu(), rtol=1e-5, atol=1e-5, what="round trip")
+        assert_close(ld + ldi, torch.zeros(()), rtol=0, atol=1e-4, what="log-det cancel")

@@ -107,6 +107,15 @@ def test_state_dict_layout_matches_reference():
     fx = fixture("g9_diag_gaussian")
     assert _entries(nf.distributions.DiagGaussian(64)) == _ref_entries(fx, "d64_Tnone")
 
+    # Glow block: keys and order of the reference (conv conditioner, LU 1x1 conv, ActNorm)
+    fx = fixture("g11_glow_multiscale")
+    blk = nf.flows.GlowBlock(12, 16)
+    ref = [e for e in _ref_entries(fx, "glow") if e[0].startswith("flows.1.0.")]
+    fixed = ("P", "sign_S", "eye", "data_dep_init_done")
+    got = [("flows.1.0." + k, s) for k, s in _entries(blk) if k.split(".")[-1] not in fixed]
+    assert got == ref
+    assert {k.split(".")[-1] for k in blk.state_dict()} >= set(fixed)
+
 
 def test_initialisation_conventions():
     m = nf.flows.CoupledRationalQuadraticSpline(8, 2, 16, 8)

@@ -9,7 +9,8 @@ import torch
 import torch.nn.functional as F
 
 from helpers import (fixture, T, state_for, assert_close, oracle_rqs_coupling,
-                     oracle_c3_stack, oracle_affine_stack)
+                     oracle_c3_stack, oracle_affine_stack, oracle_crqs_stack,
+                     oracle_glow_multiscale, glow_state)
 from oracle import rqs as OR, masks as OM, nets as ON, layers as OL
 
 F32 = dict(rtol=2e-6, atol=2e-6)
@@ -199,3 +200,28 @@ def test_affine_stacks(name, tag, layers, d, seed):
         z, lq = st.sample_from(T(fx["eps"], dt))
         assert_close(z, fx[tag + "/s_z" + suf], what="sample z", **tol)
         assert_close(lq, fx[tag + "/s_logq" + suf], what="sample log_q", **tol)
+
+
+def test_g13_c5_layer_shape():
+    """Config C5's layer shape (D=1024, K=16, ResidualNet 512 -> 24064), 2 layers."""
+    fx = fixture("g13_c5_shape")
+    for dt, suf, tol in ((torch.float32, "32", dict(rtol=1e-5, atol=2e-4)), (torch.float64, "64", F64)):
+        sd, _ = state_for(fx, "c5", 1301, dt, final_gain=1.0)
+        st = oracle_crqs_stack(sd, 2, 16, 3.0, 128)
+        assert_close(st.log_prob(T(fx["x"], dt)), fx["c5/lp" + suf], what="log_prob", **tol)
+        z, lq = st.sample_from(T(fx["eps"], dt))
+        assert_close(z, fx["c5/s_z" + suf], what="sample z", **tol)
+        assert_close(lq, fx["c5/s_logq" + suf], what="sample log_q", **tol)
+
+
+def test_g11_glow_multiscale():
+    """Config C4's family: MultiscaleFlow of GlowBlocks (affine coupling with a conv
+    conditioner and sigmoid scale map, LU 1x1 convolution, ActNorm) + Squeeze / Merge."""
+    fx = fixture("g11_glow_multiscale")
+    for dt, suf, tol in ((torch.float32, "32", dict(rtol=1e-5, atol=1e-3)), (torch.float64, "64", F64)):
+        sd = glow_state(fx, 1101, dt)
+        ms = oracle_glow_multiscale(sd)
+        assert_close(ms.log_prob(T(fx["x"], dt)), fx["glow/lp" + suf], what="log_prob", **tol)
+        z, lq = ms.sample_from([T(fx["eps0"], dt), T(fx["eps1"], dt)])
+        assert_close(z, fx["glow/s_z" + suf], what="sample z", **tol)
+        assert_close(lq, fx["glow/s_logq" + suf], what="sample log_q", **tol)

@@ -83,3 +83,91 @@ class NormalizingFlow(nn.Module):
 
     def load(self, path):
         self.load_state_dict(torch.load(path, weights_only=True))
+
+
+class MultiscaleFlow(nn.Module):
+    """Multiscale (RealNVP / Glow) container: per level a list of flows, a Merge between
+    levels and one base distribution per level.  Reference: normflow/core.py:271-399
+    (sample :310-340, log_prob :342-367).  Class-conditional bases are out of scope."""
+
+    def __init__(self, q0, flows, merges, transform=None, class_cond=True):
+        super().__init__()
+        if class_cond and any(not hasattr(q, 'from_noise') for q in q0):
+            raise NotImplementedError("class-conditional base distributions are out of scope; "
+                                      "use DiagGaussian bases with class_cond=False")
+        self.q0 = nn.ModuleList(q0)
+        self.num_levels = len(self.q0)
+        self.flows = nn.ModuleList([nn.ModuleList(f) for f in flows])
+        self.merges = nn.ModuleList(merges)
+        self.transform = transform
+        self.class_cond = False
+
+    def forward(self, x, y=None):
+        return -self.log_prob(x, y)
+
+    def forward_kld(self, x, y=None):
+        raise NotImplementedError("training objectives need the VJP kernels (SURVEY 8f row 1)")
+
+    def log_prob(self, x, y=None):
+        """core.py:348-367: optional input transform, then per level (finest last) the
+        flows inverted, the split-off half scored by that level's base."""
+        log_q = 0
+        z = x
+        if self.transform is not None:
+            z, log_det = self.transform.inverse(z)
+            log_q = log_q + log_det
+        for i in range(self.num_levels - 1, -1, -1):
+            for flow in reversed(self.flows[i]):
+                z, log_det = flow.inverse(z)
+                log_q = log_q + log_det
+            if i > 0:
+                [z, z_], log_det = self.merges[i - 1].inverse(z)
+                log_q = log_q + log_det
+            else:
+                z_ = z
+            log_q = log_q + self.q0[i].log_prob(z_)
+        return log_q
+
+    def sample(self, num_samples=1, y=None, temperature=None):
+        if temperature is not None:
+            self.set_temperature(temperature)
+        noise = [torch.randn((num_samples,) + q.shape, dtype=q.loc.dtype, device=q.loc.device) for q in self.q0]
+        out = self.sample_from(noise)
+        if temperature is not None:
+            self.reset_temperature()
+        return out
+
+    def sample_from(self, noise):
+        """core.py:320-340 with the per-level standard-normal draws supplied."""
+        z, log_q = None, None
+        for i in range(self.num_levels):
+            z_, log_q_ = self.q0[i].from_noise(noise[i])
+            if i == 0:
+                z, log_q = z_, log_q_
+            else:
+                log_q = log_q + log_q_
+                z, log_det = self.merges[i - 1]([z, z_])
+                log_q = log_q - log_det
+            for flow in self.flows[i]:
+                z, log_det = flow(z)
+                log_q = log_q - log_det
+        if self.transform is not None:
+            z, log_det = self.transform(z)
+            log_q = log_q - log_det
+        return z, log_q
+
+    def set_temperature(self, temperature):
+        for q0 in self.q0:
+            if hasattr(q0, 'temperature'):
+                q0.temperature = temperature
+            else:
+                raise NotImplementedError('One base function does not support temperature annealed sampling')
+
+    def reset_temperature(self):
+        self.set_temperature(None)
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path, weights_only=True))

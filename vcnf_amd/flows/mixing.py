@@ -1,6 +1,10 @@
-"""Channel permutations as a HIP column gather.
-Reference: normflow/flows/mixing.py:10-54 (Permute)."""
+"""Channel mixing layers.  Permutations are a HIP column gather; the invertible 1x1
+convolution is a dense C x C contraction with a parameter-only log-det and runs on
+PyTorch-ROCm (not a hand-kernel target).
+Reference: normflow/flows/mixing.py:10-54 (Permute), :57-128 (Invertible1x1Conv)."""
 import torch
+from torch import nn
+from torch.nn import functional as F
 
 from .base import Flow
 from .. import _lib
@@ -52,3 +56,53 @@ class Permute(Flow):
 
     def inverse(self, z):
         return _lib.permute(z, self._idx32(True, z.device)), 0
+
+
+class Invertible1x1Conv(Flow):
+    """Glow's invertible 1x1 convolution on NCHW inputs.  ``use_lu``: W = P L U with a
+    fixed permutation P, unit-lower L, upper U whose diagonal is sign_S * exp(log_S)
+    (mixing.py:71-84); log|det| = sum(log_S) per pixel."""
+
+    def __init__(self, num_channels, use_lu=False):
+        super().__init__()
+        self.num_channels = num_channels
+        self.use_lu = use_lu
+        q = torch.linalg.qr(torch.randn(num_channels, num_channels))[0]
+        if use_lu:
+            p, l, u = torch.linalg.lu(q)
+            diag = u.diag()
+            self.register_buffer('P', p)
+            self.L = nn.Parameter(l)
+            self.register_buffer('sign_S', torch.sign(diag))
+            self.log_S = nn.Parameter(torch.log(torch.abs(diag)))
+            self.U = nn.Parameter(torch.triu(u, diagonal=1))
+            self.register_buffer('eye', torch.diag(torch.ones(num_channels)))
+        else:
+            self.W = nn.Parameter(q)
+
+    def _assemble_W(self, inverse=False):
+        lower = torch.tril(self.L, diagonal=-1) + self.eye
+        upper = torch.triu(self.U, diagonal=1) + torch.diag(self.sign_S * torch.exp(self.log_S))
+        if not inverse:
+            return self.P @ lower @ upper
+        # the reference inverts in fp64 and casts back (mixing.py:90-95)
+        dt = self.log_S.dtype
+        return (torch.inverse(upper.double()) @ torch.inverse(lower.double())).to(dt) @ self.P.t()
+
+    def _conv(self, z, inverse_weight):
+        if self.use_lu:
+            w = self._assemble_W(inverse=inverse_weight)
+            log_det = torch.sum(self.log_S)
+        else:
+            w = torch.inverse(self.W.double()).to(self.W.dtype) if inverse_weight else self.W
+            log_det = torch.slogdet(self.W)[1]
+        if inverse_weight:
+            log_det = -log_det
+        out = F.conv2d(z, w.view(self.num_channels, self.num_channels, 1, 1))
+        return out, log_det * z.size(2) * z.size(3)
+
+    def forward(self, z):
+        return self._conv(z, True)          # sampling direction applies W^-1 (mixing.py:100-116)
+
+    def inverse(self, z):
+        return self._conv(z, False)
