@@ -137,11 +137,18 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    # rehearsal on a box with fewer GPUs than ranks (VCNF_BENCH_BACKEND=gloo): ranks share devices
+    backend = os.environ.get("VCNF_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     nf.lib()
 
     model = build_model(device, seed=0)                      # replicated weights

@@ -76,6 +76,16 @@ int vcnf_rqs_elementwise_f32(const float* x, const float* uw, const float* uh, c
                              float* y, float* logabsdet, int64_t n,
                              const vcnf_rqs_cfg* cfg, int inverse, int32_t* bad_disc, void* stream);
 
+/* Vector-Jacobian product of vcnf_rqs_elementwise_f32 (training path; the reference
+ * obtains it from autograd over utils/splines.py:88-193).  Inputs as the forward call
+ * plus the upstream gradients g_y[n], g_logabsdet[n]; outputs g_x[n] and dense
+ * g_uw[n,K], g_uh[n,K], g_ud[n, K-1 | K+1].  K <= 64. */
+int vcnf_rqs_elementwise_bwd_f32(const float* x, const float* uw, const float* uh, const float* ud,
+                                 int64_t ld_w, int64_t ld_h, int64_t ld_d,
+                                 const float* g_y, const float* g_logabsdet,
+                                 float* g_x, float* g_uw, float* g_uh, float* g_ud, int64_t n,
+                                 const vcnf_rqs_cfg* cfg, int inverse, void* stream);
+
 /* One RQS coupling layer on x[B,D] -> y[B,D].
  * Replaces Coupling.forward / .inverse (flows/neural_spline/coupling.py:70-96 /
  * :98-125) minus the conditioner call, PiecewiseCoupling._coupling_transform

@@ -527,12 +527,13 @@ def test_affine_const_flow_vs_oracle(hip):
                 assert_close(ld, want_ld, what=dirn + " ld", rtol=1e-5, atol=1e-5)
 
 
-def test_requires_grad_is_refused(hip):
-    m = nf.flows.CoupledRationalQuadraticSpline(8, 1, 16).cuda()
+def test_plain_kernel_wrappers_refuse_requires_grad(hip):
+    """The raw kernel wrappers never drop a gradient silently: outside vcnf_amd.autograd a
+    tensor that requires grad raises (the layers route through autograd instead)."""
+    x = torch.rand(4, 8, device="cuda")
+    uw = torch.randn(4, 8, 5, device="cuda", requires_grad=True)
     with pytest.raises(NotImplementedError):
-        m.inverse(torch.randn(4, 8, device="cuda"))     # grad mode on, weights require grad
-    with pytest.raises(NotImplementedError):
-        nf.NormalizingFlow(nf.distributions.DiagGaussian(8), [m]).forward_kld(torch.randn(4, 8, device="cuda"))
+        _lib.rqs_elementwise(x, uw, uw.detach(), torch.randn(4, 8, 6, device="cuda"), _lib.make_cfg(5, None), False)
 
 
 # ---------------------------------------------------------------- full-size properties (BASELINE configs)

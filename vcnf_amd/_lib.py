@@ -36,6 +36,8 @@ PROTOTYPES = {
     "vcnf_status_string": ([_INT], ctypes.c_char_p),
     "vcnf_rqs_elementwise_f32": ([_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _I64,
                                   ctypes.POINTER(RqsCfg), _INT, _P, _P], _INT),
+    "vcnf_rqs_elementwise_bwd_f32": ([_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _I64,
+                                      ctypes.POINTER(RqsCfg), _INT, _P], _INT),
     "vcnf_rqs_coupling_f32": ([_P, _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _I64,
                                ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P], _INT),
     "vcnf_rqs_conditioner_input_f32": ([_P, _I64, _I32, _P, _I32, _P, _I32, _P, _P, _P,
@@ -105,9 +107,10 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def require_device(*tensors):
-    """Every tensor must be an fp32 tensor on one HIP device; autograd through
-    the kernels is not available (VJP kernels: SURVEY 8f row 1)."""
+def require_device(*tensors, allow_grad=False):
+    """Every tensor must be an fp32 tensor on one HIP device.  Autograd reaches the
+    kernels only through vcnf_amd.autograd (the spline VJP kernel); a plain wrapper
+    called with a tensor that requires grad raises rather than silently dropping it."""
     dev = None
     for t in tensors:
         if t is None:
@@ -120,10 +123,10 @@ def require_device(*tensors):
             dev = t.device
         elif t.device != dev:
             raise VcnfError("tensors on different devices: %s vs %s" % (dev, t.device))
-        if torch.is_grad_enabled() and t.requires_grad:
+        if not allow_grad and torch.is_grad_enabled() and t.requires_grad:
             raise NotImplementedError(
-                "vcnf_amd: the HIP bijector kernels have no backward pass yet; evaluate under "
-                "torch.no_grad() (training path = SURVEY 8f row 1)")
+                "vcnf_amd: this HIP kernel has no backward pass; evaluate under torch.no_grad() "
+                "(differentiable: the RQS couplings via vcnf_amd.autograd, SURVEY 8f row 1)")
     return dev
 
 
@@ -167,9 +170,9 @@ def check_discriminant(device="cuda"):
 
 
 # ---------------------------------------------------------------- wrappers
-def rqs_elementwise(x, uw, uh, ud, cfg, inverse):
+def rqs_elementwise(x, uw, uh, ud, cfg, inverse, allow_grad=False):
     """x [...]; uw, uh [..., K]; ud [..., K-1 | K+1] (last dim contiguous)."""
-    dev = require_device(x, uw, uh, ud)
+    dev = require_device(x, uw, uh, ud, allow_grad=allow_grad)
     shape = x.shape
     k = cfg.num_bins
     nd = k - 1 if cfg.tails == TAILS_LINEAR else k + 1
@@ -195,6 +198,28 @@ def rqs_elementwise(x, uw, uh, ud, cfg, inverse):
                                             _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
     _check(st, "vcnf_rqs_elementwise_f32")
     return y.view(shape), lad.view(shape)
+
+
+def rqs_elementwise_bwd(x, uw, uh, ud, gy, glad, cfg, inverse):
+    """VJP of rqs_elementwise: returns (g_x, g_uw, g_uh, g_ud), shapes of the inputs."""
+    dev = require_device(x, uw, uh, ud, gy, glad, allow_grad=True)
+    k = cfg.num_bins
+    nd = k - 1 if cfg.tails == TAILS_LINEAR else k + 1
+    shape = x.shape
+    xf = x.detach().reshape(-1).contiguous()
+    w2 = uw.detach().reshape(-1, k).contiguous()
+    h2 = uh.detach().reshape(-1, k).contiguous()
+    d2 = ud.detach().reshape(-1, nd).contiguous()
+    gyf = gy.detach().reshape(-1).contiguous()
+    glf = glad.detach().reshape(-1).contiguous()
+    gx = torch.empty_like(xf)
+    gw, gh, gd = torch.empty_like(w2), torch.empty_like(h2), torch.empty_like(d2)
+    with torch.cuda.device(dev):
+        st = lib().vcnf_rqs_elementwise_bwd_f32(_ptr(xf), _ptr(w2), _ptr(h2), _ptr(d2), k, k, nd,
+                                               _ptr(gyf), _ptr(glf), _ptr(gx), _ptr(gw), _ptr(gh), _ptr(gd),
+                                               xf.numel(), ctypes.byref(cfg), int(bool(inverse)), _stream())
+    _check(st, "vcnf_rqs_elementwise_bwd_f32")
+    return gx.view(shape), gw.view(shape + (k,)), gh.view(shape + (k,)), gd.view(shape + (nd,))
 
 
 def rqs_coupling(x, params, tf_idx, id_idx, shared, cfg, inverse, logdet=None, sign=1.0):

@@ -7,8 +7,8 @@ straight into the running ``log_q`` inside the coupling kernel (one [B] buffer
 for the whole stack, no per-layer allocation or add); every other Flow goes
 through the plain ``(z, log_det)`` contract.
 
-Training objectives (forward_kld / reverse_kld / reverse_alpha_div) need the
-VJP kernels of SURVEY 8f row 1 and raise until those exist.  The reference's
+Training objectives (forward_kld / reverse_kld / reverse_alpha_div) differentiate through
+vcnf_amd.autograd (the spline VJP kernel).  The reference's
 categorical-dequantisation branch is out of scope; ``categoricals`` is always
 defined (None) so ``sample`` follows core.py:150-155 instead of failing with
 the AttributeError the reference has at this HEAD.
@@ -67,15 +67,79 @@ class NormalizingFlow(nn.Module):
                 log_q -= log_det
         return z, log_q
 
-    # ------------------------------------------------------------ objectives (next row)
-    def forward_kld(self, x, extended=False):
-        raise NotImplementedError("training objectives need the VJP kernels (SURVEY 8f row 1)")
+    # ------------------------------------------------------------ objectives
+    def _pull(self, z, context=None, trace=None):
+        """log q of given points through the plain ``(z, log_det)`` contract, optionally
+        recording each layer's output and log-det (the reference's ``extended`` lists)."""
+        log_q = torch.zeros(len(z), dtype=z.dtype, device=z.device)
+        for flow in reversed(self.flows):
+            ctx = {'context': context} if (context is not None and getattr(flow, 'takes_context', False)) else {}
+            z, log_det = flow.inverse(z, **ctx)
+            if trace is not None:
+                trace[0].append(z.detach().cpu().numpy())
+                trace[1].append(log_det.detach().cpu().numpy())
+            log_q = log_q + log_det
+        return log_q + self.q0.log_prob(z)
 
-    def reverse_kld(self, num_samples=1, beta=1., score_fn=True, extended=False):
-        raise NotImplementedError("training objectives need the VJP kernels (SURVEY 8f row 1)")
+    def forward_kld(self, x, extended=False, context=None):
+        """-mean log q(x) (core.py:30-65).  ``extended``: also the per-layer latents and
+        log-dets as numpy arrays and the per-sample log q."""
+        if not extended:
+            return -torch.mean(self.log_prob(x, context))
+        trace = ([], [])
+        log_q = self._pull(x, context, trace)
+        return -torch.mean(log_q), trace[0], trace[1], log_q
 
-    def reverse_alpha_div(self, num_samples=1, alpha=1, dreg=False, extended=False):
-        raise NotImplementedError("training objectives need the VJP kernels (SURVEY 8f row 1)")
+    def _frozen_log_q(self, z, context):
+        """log q(z) with the parameters held constant (core.py:87-95 / :124-131): the path
+        derivative estimators differentiate through z only."""
+        params = [p for p in self.parameters() if p.requires_grad]
+        for p in params:
+            p.requires_grad = False
+        try:
+            return self._pull(z, context)
+        finally:
+            for p in params:
+                p.requires_grad = True
+
+    def reverse_kld(self, num_samples=1, beta=1., score_fn=True, extended=False, context=None):
+        """mean log q(z) - beta * mean log p(z), z ~ q (core.py:67-100)."""
+        z, log_q = self.q0(num_samples)
+        trace = ([], []) if extended else None
+        for flow in self.flows:
+            ctx = {'context': context} if (context is not None and getattr(flow, 'takes_context', False)) else {}
+            z, log_det = flow(z, **ctx)
+            if trace is not None:
+                trace[0].append(z.detach().cpu().numpy())
+                trace[1].append(log_det.detach().cpu().numpy())
+            log_q = log_q - log_det
+        if not score_fn:
+            log_q = self._frozen_log_q(z, context)
+        log_p = self.p.log_prob(z)
+        loss = torch.mean(log_q) - beta * torch.mean(log_p)
+        if extended:
+            return loss, trace[0], trace[1], log_p, log_q
+        return loss
+
+    def reverse_alpha_div(self, num_samples=1, alpha=1, dreg=False, extended=False, context=None):
+        """Alpha divergence with samples from q (core.py:101-141); ``dreg``: the doubly
+        reparametrised estimator."""
+        import numpy as np
+        z, log_q = self.sample(num_samples, context)
+        log_p = self.p.log_prob(z)
+        if dreg:
+            w_const = torch.exp(log_p - log_q).detach()
+            log_q = self._frozen_log_q(z, context)
+            w = torch.exp(log_p - log_q)
+            w_alpha = w_const ** alpha
+            w_alpha = w_alpha / torch.mean(w_alpha)
+            weights = (1 - alpha) * w_alpha + alpha * w_alpha ** 2
+            loss = -alpha * torch.mean(weights * torch.log(w))
+        else:
+            loss = np.sign(alpha - 1) * torch.logsumexp(alpha * (log_p - log_q), 0)
+        if extended:
+            return loss, [], []
+        return loss
 
     # ------------------------------------------------------------ checkpoints
     def save(self, path):

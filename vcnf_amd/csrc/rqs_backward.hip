@@ -1,0 +1,275 @@
+// Vector-Jacobian product of the rational-quadratic spline (training path).
+//
+// Given upstream gradients (g_y, g_lad) of one spline evaluation y, lad = RQS(x; uw, uh, ud)
+// the kernel re-evaluates the element (same arithmetic as rqs_math.hpp) and walks the
+// computation backwards by hand: bin formulas -> selected knots -> cumulative widths ->
+// softmax -> logits, and the two knot derivatives through softplus.  The reference gets
+// these gradients from PyTorch autograd over ~40 ATen kernels (utils/splines.py:88-193);
+// here it is one pass per element.  The sampling direction (inverse spline) uses the
+// implicit-function identities on the forward map F(v) = u:
+//     dv/du = 1/F_v,   dv/dtheta = -F_theta / F_v,   lad_inv = -lad_fwd(v).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vcnf_hip.h"
+#include "rqs_math.hpp"
+
+namespace vcnf {
+
+constexpr int kBwdBlock = 256;
+constexpr int kBwdMaxK = 64;
+
+struct BwdArgs {
+  const float *x, *uw, *uh, *ud;
+  long long ld_w, ld_h, ld_d;
+  const float *gy, *glad;
+  float *gx, *guw, *guh, *gud;     // gradients, same strides as the logits (dense rows)
+  long long n;
+  int nd;                          // derivative logits per element
+  RqsConst c;
+};
+
+// gradient of softplus (beta 1, threshold 20)
+__device__ __forceinline__ float softplus_grad(float v) {
+  return v > 20.f ? 1.f : div_nr(1.f, 1.f + hw_exp2(-v * kLog2e));
+}
+
+// Reverse pass through rqs_bin_eval's forward branch: inputs the bin (xl, w, yl, h, d0, d1),
+// the point x and upstream (gy, gl); outputs gradients w.r.t. all seven.
+struct BinGrad {
+  float gx, gxl, gw, gyl, gh, gd0, gd1;
+};
+
+// Adjoint of the bin-coordinate map  (t, s, h, d0, d1) -> (y - yl, lad):
+//   y - yl = h (s t^2 + d0 t(1-t)) / Q,   Q = s + (d0 + d1 - 2 s) t(1-t)
+//   lad    = log(s^2 (d1 t^2 + 2 s t(1-t) + d0 (1-t)^2)) - 2 log Q          (splines.py:179-191)
+// gh is the direct dependence on h (through the numerator), not the one through s = h / w.
+struct CoreGrad {
+  float gt, gs, gh, gd0, gd1;
+};
+
+__device__ __forceinline__ CoreGrad bin_core_vjp(float t, float s, float h, float d0, float d1, float gy, float gl) {
+  const float omt = 1.f - t;
+  const float a = t * omt;
+  const float e = d0 + d1 - 2.f * s;
+  const float inner = s * t * t + d0 * a;
+  const float N = h * inner;
+  const float Q = s + e * a;
+  const float M = d1 * t * t + 2.f * s * a + d0 * omt * omt;
+  const float rQ = 1.f / Q;
+  const float g_dn = gl / (s * s * M);
+  const float g_Q = -2.f * gl * rQ - gy * N * rQ * rQ;
+  const float g_N = gy * rQ;
+  const float g_M = s * s * g_dn;
+  const float g_in = h * g_N;
+  const float g_e = a * g_Q;
+  const float g_a = 2.f * s * g_M + e * g_Q + d0 * g_in;
+  const float g_omt = 2.f * d0 * omt * g_M + t * g_a;
+  CoreGrad r;
+  r.gs = 2.f * s * M * g_dn + 2.f * a * g_M + g_Q + t * t * g_in - 2.f * g_e;
+  r.gt = 2.f * d1 * t * g_M + 2.f * s * t * g_in + omt * g_a - g_omt;
+  r.gh = inner * g_N;
+  r.gd0 = omt * omt * g_M + a * g_in + g_e;
+  r.gd1 = t * t * g_M + g_e;
+  return r;
+}
+
+// Density direction: y = F(x), lad = log F'(x), with t = (x - xl) / w and s = h / w.
+__device__ __forceinline__ BinGrad bin_forward_vjp(float x, const RqsBin& b, float gy, float gl) {
+  const float rw = 1.f / b.w;
+  const float s = b.h * rw;
+  const float t = (x - b.xl) * rw;
+  const CoreGrad c = bin_core_vjp(t, s, b.h, b.d0, b.d1, gy, gl);
+  BinGrad r;
+  r.gx = c.gt * rw;
+  r.gxl = -r.gx;
+  r.gw = -(c.gt * t + c.gs * s) * rw;
+  r.gh = c.gh + c.gs * rw;
+  r.gyl = gy;
+  r.gd0 = c.gd0;
+  r.gd1 = c.gd1;
+  return r;
+}
+
+// Sampling direction: v = xl + w r with r the root of  h phi(r; s, d0, d1) = u - yl,  lad = -log F'(v).
+// The root is differentiated implicitly IN BIN COORDINATES (dr/du = 1 / (h phi_r), dr/ds = -phi_s / phi_r,
+// ...): written per unit x the width gradient is a difference of two terms of size L_t / w that
+// agree to several digits in narrow bins; in r they never appear.  ``x`` is u.
+__device__ __forceinline__ BinGrad bin_inverse_vjp(float u, float v0, const RqsBin& b, float gy, float gl) {
+  const float rw = 1.f / b.w;
+  const float s = b.h * rw;
+  const float target = u - b.yl;
+  float r = fminf(fmaxf((v0 - b.xl) * rw, 0.f), 1.f);
+  // The closed-form root leaves a residual of up to tens of ulps of u in steep bins, which the
+  // curvature of log F' magnifies; two Newton steps on the fp32 forward map remove it (the
+  // value the forward call returned to the caller is not changed).
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const float omr = 1.f - r, a = r * omr;
+    const float Q = s + (b.d0 + b.d1 - 2.f * s) * a;
+    const float f = b.h * (s * r * r + b.d0 * a) / Q;
+    const float fr = b.h * s * (b.d1 * r * r + 2.f * s * a + b.d0 * omr * omr) / (Q * Q);
+    r = fminf(fmaxf(r - (f - target) / fr, 0.f), 1.f);
+  }
+  const CoreGrad F = bin_core_vjp(r, s, b.h, b.d0, b.d1, 1.f, 0.f);
+  const CoreGrad L = bin_core_vjp(r, s, b.h, b.d0, b.d1, 0.f, 1.f);
+  const float gr = gy * b.w - gl * L.gt;
+  const float gu = gr / F.gt;
+  const float gs = -gu * F.gs - gl * L.gs;
+  BinGrad o;
+  o.gx = gu;
+  o.gyl = -gu;
+  o.gxl = gy;
+  o.gw = gy * r - gs * s * rw;
+  o.gh = -gu * F.gh + gs * rw;
+  o.gd0 = -gu * F.gd0 - gl * L.gd0;
+  o.gd1 = -gu * F.gd1 - gl * L.gd1;
+  return o;
+}
+
+template <int KT, bool INV>
+__global__ __launch_bounds__(kBwdBlock) void rqs_elementwise_bwd_kernel(const BwdArgs a) {
+  const RqsConst& c = a.c;
+  const int K = KT > 0 ? KT : c.K;
+  constexpr int KA = KT > 0 ? KT : kBwdMaxK;
+  for (long long i = (long long)blockIdx.x * kBwdBlock + threadIdx.x; i < a.n; i += (long long)gridDim.x * kBwdBlock) {
+    const float x = a.x[i];
+    const float gy = a.gy[i], gl = a.glad[i];
+    const float* uw = a.uw + i * a.ld_w;
+    const float* uh = a.uh + i * a.ld_h;
+    const float* ud = a.ud + i * a.ld_d;
+    float* guw = a.guw + i * K;
+    float* guh = a.guh + i * K;
+    float* gud = a.gud + i * a.nd;
+    if (c.tails == 1 && !((x >= c.lo_x) && (x <= c.hi_x))) {     // identity outside: dy/dx = 1
+      a.gx[i] = gy;
+      for (int k = 0; k < K; ++k) { guw[k] = 0.f; guh[k] = 0.f; }
+      for (int k = 0; k < a.nd; ++k) gud[k] = 0.f;
+      continue;
+    }
+    // ---- forward pieces: softmax probabilities and knots
+    float pw[KA], ph[KA];
+    float mw = -INFINITY, mh = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { mw = fmaxf(mw, uw[k]); mh = fmaxf(mh, uh[k]); }
+    const float sc2 = c.wh_scale * kLog2e;
+    float sw = 0.f, sh = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      pw[k] = hw_exp2((uw[k] - mw) * sc2);
+      ph[k] = hw_exp2((uh[k] - mh) * sc2);
+      sw += pw[k];
+      sh += ph[k];
+    }
+    const float rsw = div_nr(1.f, sw), rsh = div_nr(1.f, sh);
+    float cw = 0.f, ch = 0.f, xl = c.lo_x, yl = c.lo_y;
+    RqsBin b;
+    int bin = 0;
+    b.xl = xl; b.yl = yl; b.w = 1.f; b.h = 1.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      pw[k] *= rsw;
+      ph[k] *= rsh;
+      cw += fmaf(pw[k], c.free_w, c.min_w);
+      ch += fmaf(ph[k], c.free_h, c.min_h);
+      const float xr = (k == K - 1) ? c.hi_x : fmaf(c.span_x, cw, c.lo_x);
+      const float yr = (k == K - 1) ? c.hi_y : fmaf(c.span_y, ch, c.lo_y);
+      const bool take = (k == 0) || (INV ? (x >= yl) : (x >= xl));
+      if (take) { bin = k; b.xl = xl; b.w = xr - xl; b.yl = yl; b.h = yr - yl; }
+      xl = xr; yl = yr;
+    }
+    // knot derivatives of the bin: logit index (or boundary constant)
+    const int i0 = c.tails == 1 ? bin - 1 : bin;            // logit of the left knot (-1: boundary)
+    const int i1 = c.tails == 1 ? bin : bin + 1;            // logit of the right knot (nd: boundary)
+    const bool has0 = i0 >= 0, has1 = i1 < a.nd;
+    const float l0 = has0 ? ud[i0] : c.edge_logit, l1 = has1 ? ud[i1] : c.edge_logit;
+    b.d0 = c.min_d + softplus_f(l0);
+    b.d1 = c.min_d + softplus_f(l1);
+
+    BinGrad g;
+    if (!INV) {
+      g = bin_forward_vjp(x, b, gy, gl);
+    } else {
+      // v = F^-1(u): solve as the forward kernel does, then differentiate the root
+      float v, lad_inv;
+      bool bad = false;
+      rqs_bin_eval<true>(x, b, v, lad_inv, bad);
+      g = bin_inverse_vjp(x, v, b, gy, gl);
+    }
+    a.gx[i] = g.gx;
+    // ---- knots -> cumulative widths -> softmax -> logits
+    // X_bin carries (gxl - gw), X_bin+1 carries gw; the end knots are constants.
+    const float gXl = (bin >= 1) ? (g.gxl - g.gw) : 0.f;
+    const float gXr = (bin + 1 <= K - 1) ? g.gw : 0.f;
+    const float gYl = (bin >= 1) ? (g.gyl - g.gh) : 0.f;
+    const float gYr = (bin + 1 <= K - 1) ? g.gh : 0.f;
+    // dX_k/dW_i = span for i < k  ->  gW_i = span * (gXl [i < bin] + gXr [i < bin+1])
+    float dotw = 0.f, doth = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float gWk = c.span_x * c.free_w * ((k < bin ? gXl : 0.f) + (k < bin + 1 ? gXr : 0.f));
+      const float gHk = c.span_y * c.free_h * ((k < bin ? gYl : 0.f) + (k < bin + 1 ? gYr : 0.f));
+      dotw += pw[k] * gWk;
+      doth += ph[k] * gHk;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float gWk = c.span_x * c.free_w * ((k < bin ? gXl : 0.f) + (k < bin + 1 ? gXr : 0.f));
+      const float gHk = c.span_y * c.free_h * ((k < bin ? gYl : 0.f) + (k < bin + 1 ? gYr : 0.f));
+      guw[k] = c.wh_scale * pw[k] * (gWk - dotw);
+      guh[k] = c.wh_scale * ph[k] * (gHk - doth);
+    }
+    for (int k = 0; k < a.nd; ++k) gud[k] = 0.f;
+    if (has0) gud[i0] = g.gd0 * softplus_grad(l0);
+    if (has1) gud[i1] = g.gd1 * softplus_grad(l1);
+  }
+}
+
+template <bool INV>
+static void launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t st) {
+  switch (a.c.K) {
+    case 4: hipLaunchKernelGGL((rqs_elementwise_bwd_kernel<4, INV>), grid, dim3(kBwdBlock), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((rqs_elementwise_bwd_kernel<8, INV>), grid, dim3(kBwdBlock), 0, st, a); break;
+    case 10: hipLaunchKernelGGL((rqs_elementwise_bwd_kernel<10, INV>), grid, dim3(kBwdBlock), 0, st, a); break;
+    case 16: hipLaunchKernelGGL((rqs_elementwise_bwd_kernel<16, INV>), grid, dim3(kBwdBlock), 0, st, a); break;
+    default: hipLaunchKernelGGL((rqs_elementwise_bwd_kernel<0, INV>), grid, dim3(kBwdBlock), 0, st, a); break;
+  }
+}
+
+}  // namespace vcnf
+
+using namespace vcnf;
+
+extern "C" int vcnf_rqs_elementwise_bwd_f32(const float* x, const float* uw, const float* uh, const float* ud,
+                                            int64_t ld_w, int64_t ld_h, int64_t ld_d,
+                                            const float* g_y, const float* g_logabsdet,
+                                            float* g_x, float* g_uw, float* g_uh, float* g_ud, int64_t n,
+                                            const vcnf_rqs_cfg* cfg, int inverse, void* stream) {
+  if (!cfg) return VCNF_ERR_NULL;
+  const int K = cfg->num_bins;
+  if (K < 1 || K > kBwdMaxK) return VCNF_ERR_SHAPE;
+  if (cfg->tails != VCNF_TAILS_NONE && cfg->tails != VCNF_TAILS_LINEAR) return VCNF_ERR_UNSUPPORTED;
+  if (cfg->tails == VCNF_TAILS_LINEAR && K < 2) return VCNF_ERR_SHAPE;
+  if ((double)cfg->min_bin_width * K > 1.0 || (double)cfg->min_bin_height * K > 1.0) return VCNF_ERR_VALUE;
+  if (n < 0 || ld_w < 0 || ld_h < 0 || ld_d < 0) return VCNF_ERR_SHAPE;
+  if (n == 0) return VCNF_OK;
+  if (!x || !uw || !uh || !ud || !g_y || !g_logabsdet || !g_x || !g_uw || !g_uh || !g_ud) return VCNF_ERR_NULL;
+  BwdArgs a;
+  a.x = x; a.uw = uw; a.uh = uh; a.ud = ud; a.ld_w = ld_w; a.ld_h = ld_h; a.ld_d = ld_d;
+  a.gy = g_y; a.glad = g_logabsdet; a.gx = g_x; a.guw = g_uw; a.guh = g_uh; a.gud = g_ud; a.n = n;
+  a.nd = cfg->tails == VCNF_TAILS_LINEAR ? K - 1 : K + 1;
+  RqsConst& c = a.c;
+  c.K = K; c.tails = cfg->tails;
+  c.lo_x = cfg->left; c.hi_x = cfg->right; c.span_x = (float)((double)cfg->right - (double)cfg->left);
+  c.lo_y = cfg->bottom; c.hi_y = cfg->top; c.span_y = (float)((double)cfg->top - (double)cfg->bottom);
+  c.min_w = cfg->min_bin_width; c.min_h = cfg->min_bin_height; c.min_d = cfg->min_derivative;
+  c.free_w = (float)(1.0 - (double)cfg->min_bin_width * K);
+  c.free_h = (float)(1.0 - (double)cfg->min_bin_height * K);
+  c.wh_scale = cfg->wh_scale;
+  c.edge_logit = (float)log(exp(1.0 - (double)cfg->min_derivative) - 1.0);
+  const long long blocks = (n + kBwdBlock - 1) / kBwdBlock;
+  dim3 grid((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16));
+  if (inverse) launch_bwd<true>(a, grid, (hipStream_t)stream);
+  else launch_bwd<false>(a, grid, (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
+}

@@ -193,8 +193,46 @@ class PiecewiseRationalQuadraticCoupling(Flow):
             return net.trunk(first, context)
         return net(first, context) if context is not None else net(first)
 
+    def _needs_grad(self, inputs, context):
+        if not torch.is_grad_enabled():
+            return False
+        if inputs.requires_grad or (context is not None and context.requires_grad):
+            return True
+        return any(p.requires_grad for p in self.parameters())
+
+    def _run_differentiable(self, inputs, context, sampling):
+        """Training path (coupling.py:70-125 as written there): gather / conditioner /
+        scatter are PyTorch ops, the splines and their gradients are the HIP kernels of
+        vcnf_amd.autograd."""
+        from ... import autograd
+        k = self.num_bins
+        xi = inputs[:, self.identity_features]
+        xt = inputs[:, self.transform_features]
+        lad_i = 0.0
+        uncond = self.unconditional_transform
+        if sampling and uncond is not None:
+            xi, lad_e = autograd.rqs_spline(xi, *uncond.logits(), self._cfg(False), inverse=True)
+            lad_i = lad_e.sum(dim=1)
+        params = self.transform_net(xi, context) if context is not None else self.transform_net(xi)
+        p = params.reshape(inputs.shape[0], self.num_transform_features, -1)
+        yt, lad_e = autograd.rqs_spline(xt, p[..., :k], p[..., k:2 * k], p[..., 2 * k:], self._cfg(True),
+                                        inverse=sampling)
+        lad = lad_e.sum(dim=1) + lad_i
+        if (not sampling) and uncond is not None:
+            xi, lad_e = autograd.rqs_spline(xi, *uncond.logits(), self._cfg(False), inverse=False)
+            lad = lad + lad_e.sum(dim=1)
+        out = torch.empty_like(inputs)
+        out[:, self.identity_features] = xi
+        out[:, self.transform_features] = yt
+        return out, lad
+
     def _run(self, inputs, context, sampling, log_q=None, sign=1.0):
         self._check(inputs)
+        if self._needs_grad(inputs, context):
+            out, lad = self._run_differentiable(inputs, context, sampling)
+            if log_q is not None:
+                return out, log_q.add_(lad, alpha=sign)
+            return out, (lad if sign == 1.0 else sign * lad)
         if self.fused and fused.eligible(self, context):
             # conditioner + splines in one kernel (csrc/fused_layer.hip)
             return fused.run(self, inputs, context, sampling, log_q, sign)
