@@ -62,7 +62,7 @@ def test_spline_vjp_vs_oracle_autograd(hip, tails, inverse, k):
     gy, gl = torch.randn(n, generator=g), torch.randn(n, generator=g)
 
     def oracle_grads(dtype):
-        leaves = [t.to(dtype).requires_grad_() for t in (x, uw, uh, ud)]
+        leaves = [t.clone().to(dtype).requires_grad_() for t in (x, uw, uh, ud)]
         if tails == "linear":
             y, lad = orqs.rq_spline_tails(*leaves, inverse=inverse, tails="linear", tail_bound=bound)
         else:
@@ -134,7 +134,7 @@ def test_c3_stack_parameter_gradients(hip, direction):
     names = [n for n, p in model.named_parameters()]
     want = torch.autograd.grad(want_val, [xin] + [sd64[n] for n in names], allow_unused=True)
     got_val.backward()
-    assert abs(float(got_val) - float(want_val)) < 1e-4 * max(1.0, abs(float(want_val)))
+    assert abs(float(got_val.detach()) - float(want_val.detach())) < 1e-4 * max(1.0, abs(float(want_val.detach())))
     close(xg.grad, want[0], "input gradient (%s)" % direction, atol=1e-3)
     params = dict(model.named_parameters())
     for n, w in zip(names, want[1:]):
@@ -144,3 +144,171 @@ def test_c3_stack_parameter_gradients(hip, direction):
             continue
         assert gp is not None, n + ": no gradient reached this parameter"
         close(gp, w, "%s (%s)" % (n, direction), atol=1e-3)
+
+
+# ---------------------------------------------------------------- affine family
+def _grad_compare(call, ora_fn, sd, inputs, what, atol=1e-3, loss_of=None):
+    """Backward through ``model`` on the GPU and through the oracle (fp64 and fp32) on the CPU
+    for the same scalar; compare every parameter gradient and the input gradient."""
+    loss_of = loss_of or (lambda out: out.mean())
+    model = call.__self__                      # ``call`` is a bound method of the module under test
+    model.zero_grad()
+    names = [n for n, _ in model.named_parameters()]
+
+    def oracle(dtype):
+        leaves = {k_: (v.detach().clone().to(dtype).requires_grad_() if v.is_floating_point() else v)
+                  for k_, v in sd.items()}
+        xin = [t.detach().clone().to(dtype).requires_grad_() for t in inputs]
+        val = loss_of(ora_fn(leaves, *xin))
+        gs = torch.autograd.grad(val, xin + [leaves[n] for n in names], allow_unused=True)
+        return val, gs
+    v64, g64 = oracle(torch.float64)
+    _, g32 = oracle(torch.float32)
+    xg = [dev(t.detach().clone()).requires_grad_() for t in inputs]
+    val = loss_of(call(*xg))
+    val.backward()
+    val, v64 = val.detach(), v64.detach()
+    assert abs(float(val) - float(v64)) < 1e-4 * max(1.0, abs(float(v64))), (float(val), float(v64))
+    got = [t.grad for t in xg] + [dict(model.named_parameters())[n].grad for n in names]
+    labels = ["input%d" % i for i in range(len(xg))] + names
+    for lab, a, b, b32 in zip(labels, got, g64, g32):
+        if b is None:
+            assert a is None or not a.any(), lab
+            continue
+        assert a is not None, lab + ": no gradient reached this tensor"
+        close(a, b.reshape(a.shape), "%s %s" % (what, lab), want32=b32.reshape(a.shape), atol=atol)
+
+
+@pytest.mark.parametrize("name,tag,layers,d,widths,seed", [
+    ("g10_c1_two_moons", "c1", 4, 2, [1, 32, 32, 2], 1001),
+    ("g12_c2_tabular", "c2", 8, 32, [16, 64, 64, 32], 1201)])
+@pytest.mark.parametrize("direction", ["log_prob", "sample"])
+def test_affine_stack_gradients(hip, name, tag, layers, d, widths, seed, direction):
+    """Configs C1 / C2 (AffineCouplingBlock + Permute stacks): gradient of mean log q."""
+    from helpers import oracle_affine_stack
+    fx = fixture(name)
+    sd, _ = state_for(fx, tag, seed, weight_gain=0.4 if tag == "c2" else 1.0)
+    flows = []
+    for _ in range(layers):
+        flows += [nf.flows.AffineCouplingBlock(nf.nets.MLP(widths)), nf.flows.Permute(d, mode="swap")]
+    model = nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows)
+    model.load_state_dict(sd)
+    model = model.to("cuda")
+    if direction == "log_prob":
+        _grad_compare(model.log_prob, lambda s, x: oracle_affine_stack(s, layers, d).log_prob(x), sd,
+                      [T(fx["x"])[:512]], tag + " log_prob")
+    else:
+        pick = lambda out: out[1].mean() + (out[0] ** 2).mean()
+        _grad_compare(model.sample_from, lambda s, e: oracle_affine_stack(s, layers, d).sample_from(e), sd,
+                      [T(fx["eps"])[:512]], tag + " sample", loss_of=pick)
+
+
+@pytest.mark.parametrize("sm", ["exp", "sigmoid", "sigmoid_inv", "noscale"])
+@pytest.mark.parametrize("dirn", ["forward", "inverse"])
+def test_affine_coupling_block_scale_map_gradients(hip, sm, dirn):
+    from oracle import layers as OL, nets as ON
+    fx = fixture("g6_affine")
+    d, mode = 33, "channel_inv"
+    tag = "d%d/%s/%s" % (d, sm, mode)
+    d1 = (d + 1) // 2
+    cin, cout = d - d1, d1
+    scale = sm != "noscale"
+    blk = nf.flows.AffineCouplingBlock(nf.nets.MLP([cin, 24, 24, (2 if scale else 1) * cout]), scale=scale,
+                                       scale_map=sm if scale else "exp", split_mode=mode)
+    sd, _ = state_for(fx, tag, 601 + d)
+    blk.load_state_dict(sd)
+    blk = blk.to("cuda")
+
+    def ora(s, x):
+        o = OL.AffineCouplingBlock(lambda z: ON.mlp(s, "flows.1.param_map.", z, 0.0), scale=scale,
+                                   scale_map=sm if scale else "exp", split_mode=mode)
+        return getattr(o, dirn)(x)
+    pick = lambda out: (out[0] ** 2).mean() + (out[1].mean() if torch.is_tensor(out[1]) else 0.0)
+    _grad_compare(getattr(blk, dirn), ora, sd, [T(fx["d%d/x" % d])], "%s %s" % (tag, dirn), loss_of=pick)
+
+
+@pytest.mark.parametrize("variant", ["st", "t_only", "s_only"])
+@pytest.mark.parametrize("dirn", ["forward", "inverse"])
+def test_masked_affine_gradients(hip, variant, dirn):
+    from oracle import layers as OL, nets as ON
+    fx = fixture("g7_masked_affine")
+    d = 30
+    tag = "d%d/%s" % (d, variant)
+    s = nf.nets.MLP([d, 16, d]) if variant != "t_only" else None
+    t = nf.nets.MLP([d, 16, d]) if variant != "s_only" else None
+    b = T(fx["d%d/b" % d])
+    m = nf.flows.MaskedAffineFlow(b, t, s)
+    sd, _ = state_for(fx, tag, 701 + d)
+    sd["b"] = b.view(1, -1)
+    m.load_state_dict(sd)
+    m = m.to("cuda")
+
+    def ora(st, x):
+        o = OL.MaskedAffine(st["b"].to(x.dtype),
+                            s_fn=(lambda z: ON.mlp(st, "s.", z, 0.0)) if s is not None else None,
+                            t_fn=(lambda z: ON.mlp(st, "t.", z, 0.0)) if t is not None else None)
+        return getattr(o, dirn)(x)
+    pick = lambda out: (out[0] ** 2).mean() + out[1].mean()
+    _grad_compare(getattr(m, dirn), ora, sd, [T(fx["d%d/x" % d])], "%s %s" % (tag, dirn), loss_of=pick)
+
+
+def test_glow_multiscale_gradients(hip):
+    """Config C4's family: d(mean log q)/d(theta) through GlowBlocks (4-D affine coupling with
+    sigmoid scale map, ActNorm, 1x1 convolution, squeeze, multiscale split)."""
+    from helpers import oracle_glow_multiscale, glow_state
+    from test_gpu_parity import _glow_model
+    fx = fixture("g11_glow_multiscale")
+    sd = glow_state(fx, 1101)
+    model = _glow_model()
+    model.load_state_dict(sd)
+    model = model.to("cuda")
+    _grad_compare(model.log_prob, lambda s, x: oracle_glow_multiscale(s).log_prob(x), sd, [T(fx["x"])],
+                  "glow log_prob", atol=2e-3)
+
+
+# ---------------------------------------------------------------- objectives
+def test_forward_kld_training_reduces_loss(hip):
+    """A few Adam steps of maximum likelihood on a C3-shaped stack (2 layers, context 16): the
+    loss is finite, every parameter receives a gradient, and the loss goes down."""
+    torch.manual_seed(5)
+    model = _c3_small(2).to("cuda")
+    x = torch.randn(2048, 64, device="cuda") * 0.7 + 0.3
+    ctx = torch.randn(2048, 16, device="cuda")
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad()
+        loss = model.forward_kld(x, context=ctx)
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+        opt.step()
+        losses.append(float(loss))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0] - 0.5, losses
+    with torch.no_grad():                       # evaluation path (fused kernel) agrees with the training path
+        lp_eval = model.log_prob(x, ctx)
+    lp_train = model.log_prob(x, ctx)
+    assert lp_train.requires_grad
+    assert torch.allclose(lp_eval, lp_train.detach(), rtol=1e-4, atol=2e-3)
+
+
+def test_reverse_kld_and_alpha_div(hip):
+    torch.manual_seed(6)
+    flows = []
+    for _ in range(3):
+        flows += [nf.flows.AffineCouplingBlock(nf.nets.MLP([1, 16, 16, 2], init_zeros=True)),
+                  nf.flows.Permute(2, mode="swap")]
+    target = nf.distributions.DiagGaussian(2, trainable=False).to("cuda")
+    model = nf.NormalizingFlow(nf.distributions.DiagGaussian(2), flows, p=target).to("cuda")
+    for kw in (dict(), dict(score_fn=False)):
+        model.zero_grad()
+        loss = model.reverse_kld(512, **kw)
+        loss.backward()
+        assert torch.isfinite(loss) and abs(float(loss)) < 1e-3      # identity flow, target == base
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    for kw in (dict(alpha=0.5), dict(alpha=0.5, dreg=True)):
+        model.zero_grad()
+        loss = model.reverse_alpha_div(512, **kw)
+        loss.backward()
+        assert torch.isfinite(loss)
+    out = model.forward_kld(torch.randn(64, 2, device="cuda"), extended=True)
+    assert len(out) == 4 and len(out[1]) == len(model.flows) and out[3].shape == (64,)

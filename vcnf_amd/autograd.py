@@ -4,6 +4,8 @@ RQS couplings: when gradients are required the coupling layer 
 gather / conditioner / scatter in PyTorch (all differentiable) around this op, exactly the
 structure of the reference (flows/neural_spline/coupling.py:70-125), with the spline
 arithmetic and its gradient on the HIP kernels."""
+import math
+
 import torch
 
 from . import _lib
@@ -34,39 +36,174 @@ def rqs_spline(x, uw, uh, ud, cfg, inverse=False):
                              ud.expand(x.shape + ud.shape[-1:]), cfg, inverse)
 
 
-class _HipForwardTorchBackward(torch.autograd.Function):
-    """Forward on a HIP kernel, backward by re-evaluating a PyTorch restatement of the same
-    (cheap, elementwise) op on the device and differentiating that.  Used for the end caps
-    and the affine layers, whose VJPs are two or three elementwise ops; the spline VJP has
-    its own kernel (RqsSplineFn)."""
-
-    @staticmethod
-    def forward(ctx, hip_fn, torch_fn, *tensors):
-        with torch.no_grad():
-            outs = hip_fn(*[t.detach() for t in tensors])
-        ctx.torch_fn = torch_fn
-        ctx.save_for_backward(*tensors)
-        ctx.single = torch.is_tensor(outs)
-        return outs if ctx.single else tuple(outs)
-
-    @staticmethod
-    def backward(ctx, *gouts):
-        needs = ctx.needs_input_grad[2:]
-        leaves = [t.detach().requires_grad_(n) for t, n in zip(ctx.saved_tensors, needs)]
-        with torch.enable_grad():
-            outs = ctx.torch_fn(*leaves)
-        outs = [outs] if torch.is_tensor(outs) else list(outs)
-        pairs = [(o, g) for o, g in zip(outs, gouts) if g is not None and o.requires_grad]
-        want = [l for l, n in zip(leaves, needs) if n]
-        grads = iter(torch.autograd.grad([o for o, _ in pairs], want, [g for _, g in pairs], allow_unused=True)
-                     if pairs and want else [None] * len(want))
-        return (None, None) + tuple(next(grads) if n else None for n in needs)
-
-
-def hip_forward(hip_fn, torch_fn, *tensors):
-    """``hip_fn(*tensors)`` with gradients defined by ``torch_fn(*tensors)``."""
-    return _HipForwardTorchBackward.apply(hip_fn, torch_fn, *tensors)
-
-
 def needs_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _bc(g, like):
+    """[B] upstream log-det gradient broadcast over the feature dims of ``like``."""
+    return g.reshape((-1,) + (1,) * (like.dim() - 1))
+
+
+def _sum_to_channels(t):
+    """Sum over batch and inner dims -> [C] (per-channel parameters)."""
+    return t.transpose(0, 1).reshape(t.shape[1], -1).sum(1)
+
+
+# The remaining layers are one or two elementwise ops; their forward values come from the HIP
+# kernels and their VJPs are the closed forms below, evaluated with device tensor ops.
+
+class AffineCouplingFn(torch.autograd.Function):
+    """vcnf_affine_coupling_f32.  With m the multiplier (exp(s) | 1/sigmoid(s+2) | sigmoid(s+2))
+    and q = d log m / ds:  forward  out = z m + shift, ld = sum log m;  inverse
+    out = (z - shift) / m, ld = -sum log m.  Channels outside [t_off, t_off + d_t) pass through."""
+
+    @staticmethod
+    def forward(ctx, z, param, t_off, d_t, code, inverse):
+        with torch.no_grad():
+            out, ld = _lib.affine_coupling(z, param, t_off, d_t, code, inverse)
+        ctx.save_for_backward(z if not inverse else out, param)
+        ctx.cfg = (t_off, d_t, code, inverse)
+        if ld is None:
+            ld = torch.zeros(z.shape[0], dtype=z.dtype, device=z.device)
+        return out, ld
+
+    @staticmethod
+    def backward(ctx, g_out, g_ld):
+        keep, param = ctx.saved_tensors
+        t_off, d_t, code, inverse = ctx.cfg
+        sl = slice(t_off, t_off + d_t)
+        g_t = g_out[:, sl]
+        g_z = g_out.clone()
+        if code == _lib.SCALE_NONE:
+            g_param = -g_t if inverse else g_t
+            return g_z, g_param.contiguous(), None, None, None, None
+        s = param[:, 1::2]
+        if code == _lib.SCALE_EXP:
+            m, q = torch.exp(s), None
+        else:
+            sig = torch.sigmoid(s + 2)
+            m, q = (1 / sig, sig - 1) if code == _lib.SCALE_SIGMOID else (sig, 1 - sig)
+        gl = _bc(g_ld, g_t)
+        if not inverse:
+            g_z[:, sl] = g_t * m
+            g_shift = g_t
+            g_s = g_t * keep[:, sl] * m + gl            # keep = z
+        else:
+            g_z[:, sl] = g_t / m
+            g_shift = -g_z[:, sl]
+            g_s = -(g_t * keep[:, sl]) - gl             # keep = out
+        if q is not None:
+            g_s = g_s * q
+        g_param = torch.empty_like(param)
+        g_param[:, 0::2] = g_shift
+        g_param[:, 1::2] = g_s
+        return g_z, g_param, None, None, None, None
+
+
+class MaskedAffineFn(torch.autograd.Function):
+    """vcnf_masked_affine_f32: out = b z + (1-b)(z e^s + t) | b z + (1-b)(z - t) e^-s, [B, D]."""
+
+    @staticmethod
+    def forward(ctx, z, s, t, bmask, inverse):
+        with torch.no_grad():
+            out, ld = _lib.masked_affine(z, s, t, bmask, inverse)
+        ctx.save_for_backward(z, s, t, bmask, out)
+        ctx.inverse = inverse
+        return out, ld
+
+    @staticmethod
+    def backward(ctx, g_out, g_ld):
+        z, s, t, b, out = ctx.saved_tensors
+        nb = 1 - b
+        gl = g_ld[:, None]
+        e = torch.exp(s if not ctx.inverse else -s) if s is not None else None
+        if not ctx.inverse:
+            g_z = g_out * (b + nb * e) if s is not None else g_out
+            g_s = nb * (g_out * z * e + gl) if s is not None else None
+            g_t = nb * g_out if t is not None else None
+        else:
+            g_z = g_out * (b + nb * e) if s is not None else g_out
+            # (1-b) out = (1-b)(z - t) e^-s
+            g_s = nb * (-(g_out * out) - gl) if s is not None else None
+            g_t = (-(nb * g_out * e) if s is not None else -(nb * g_out)) if t is not None else None
+        return g_z, g_s, g_t, None, None
+
+
+class AffineConstFn(torch.autograd.Function):
+    """vcnf_affine_const_f32: out = z e^s + t | (z - t) e^-s with per-channel s, t [C]."""
+
+    @staticmethod
+    def forward(ctx, z, s, t, inverse):
+        with torch.no_grad():
+            out = _lib.affine_const(z, s, t, inverse)
+        ctx.save_for_backward(z if not inverse else out, s)
+        ctx.inverse = inverse
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        keep, s = ctx.saved_tensors
+        shape = (1, -1) + (1,) * (g.dim() - 2)
+        if not ctx.inverse:
+            e = torch.exp(s).reshape(shape)
+            return g * e, _sum_to_channels(g * keep * e), _sum_to_channels(g), None
+        e = torch.exp(-s).reshape(shape)
+        g_z = g * e
+        return g_z, -_sum_to_channels(g * keep), -_sum_to_channels(g_z), None
+
+
+class PermuteFn(torch.autograd.Function):
+    """vcnf_permute_f32; the VJP is the same kernel with the opposite index vector."""
+
+    @staticmethod
+    def forward(ctx, z, idx32, back32):
+        ctx.back = back32
+        with torch.no_grad():
+            return _lib.permute(z, idx32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _lib.permute(g.contiguous(), ctx.back), None, None
+
+
+class DiagGaussianLogProbFn(torch.autograd.Function):
+    """vcnf_diag_gaussian_log_prob_f32: lp = const - sum(ls + ((z - loc) / e^ls)^2 / 2)."""
+
+    @staticmethod
+    def forward(ctx, z, loc, ls, temperature):
+        with torch.no_grad():
+            lp = _lib.diag_gaussian_log_prob(z, loc, ls, temperature)
+        ctx.save_for_backward(z, loc, ls)
+        ctx.lt = 0.0 if temperature is None else math.log(temperature)
+        return lp
+
+    @staticmethod
+    def backward(ctx, g):
+        z, loc, ls = ctx.saved_tensors
+        v = z.reshape(len(z), -1)
+        inv = torch.exp(-(ls + ctx.lt))
+        u = (v - loc) * inv
+        gu = g[:, None] * u
+        return (-(gu * inv)).reshape(z.shape), (gu * inv).sum(0), (gu * u - g[:, None]).sum(0), None
+
+
+class DiagGaussianSampleFn(torch.autograd.Function):
+    """vcnf_diag_gaussian_sample_f32: z = loc + e^ls eps, lp = const - sum(ls + eps^2 / 2)."""
+
+    @staticmethod
+    def forward(ctx, eps, loc, ls, temperature):
+        with torch.no_grad():
+            z, lp = _lib.diag_gaussian_sample(eps, loc, ls, temperature)
+        ctx.save_for_backward(eps, ls)
+        ctx.lt = 0.0 if temperature is None else math.log(temperature)
+        return z, lp
+
+    @staticmethod
+    def backward(ctx, g_z, g_lp):
+        eps, ls = ctx.saved_tensors
+        e = eps.reshape(len(eps), -1)
+        gz = g_z.reshape(len(eps), -1)
+        sig = torch.exp(ls + ctx.lt)
+        g_eps = gz * sig - g_lp[:, None] * e
+        return g_eps.reshape(eps.shape), gz.sum(0), (gz * sig * e - g_lp[:, None]).sum(0), None

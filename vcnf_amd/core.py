@@ -77,7 +77,7 @@ class NormalizingFlow(nn.Module):
             z, log_det = flow.inverse(z, **ctx)
             if trace is not None:
                 trace[0].append(z.detach().cpu().numpy())
-                trace[1].append(log_det.detach().cpu().numpy())
+                trace[1].append(torch.as_tensor(log_det).detach().cpu().numpy())
             log_q = log_q + log_det
         return log_q + self.q0.log_prob(z)
 
@@ -111,7 +111,7 @@ class NormalizingFlow(nn.Module):
             z, log_det = flow(z, **ctx)
             if trace is not None:
                 trace[0].append(z.detach().cpu().numpy())
-                trace[1].append(log_det.detach().cpu().numpy())
+                trace[1].append(torch.as_tensor(log_det).detach().cpu().numpy())
             log_q = log_q - log_det
         if not score_fn:
             log_q = self._frozen_log_q(z, context)

@@ -48,34 +48,14 @@ class DiagGaussian(BaseDistribution):
         """base.py:639-641 with the standard-normal draw supplied (parity tests
         feed the reference's captured draw; RNG streams differ across devices)."""
         loc, ls = self._flat()
-        temp = self.temperature
         if autograd.needs_grad(eps, loc, ls):
-            return autograd.hip_forward(lambda e, m, s: _lib.diag_gaussian_sample(e, m, s, temp),
-                                        lambda e, m, s: self._torch_sample(e, m, s), eps, loc, ls)
-        return _lib.diag_gaussian_sample(eps, loc, ls, temp)
+            return autograd.DiagGaussianSampleFn.apply(eps, loc, ls, self.temperature)
+        return _lib.diag_gaussian_sample(eps, loc, ls, self.temperature)
 
     def log_prob(self, z, out=None):
         """base.py:644-652.  ``out`` [B]: accumulate into it instead of allocating."""
         loc, ls = self._flat()
-        temp = self.temperature
         if autograd.needs_grad(z, loc, ls, out):
-            lp = autograd.hip_forward(lambda v, m, s: _lib.diag_gaussian_log_prob(v, m, s, temp),
-                                      lambda v, m, s: self._torch_log_prob(v, m, s), z, loc, ls)
+            lp = autograd.DiagGaussianLogProbFn.apply(z, loc, ls, self.temperature)
             return lp if out is None else out.add_(lp)
-        return _lib.diag_gaussian_log_prob(z, loc, ls, temp, logp=out)
-
-    # PyTorch restatements of the two kernels: only differentiated (training path), never
-    # used to produce values
-    def _ls(self, ls):
-        return ls if self.temperature is None else ls + float(np.log(self.temperature))
-
-    def _torch_sample(self, eps, loc, ls):
-        ls = self._ls(ls)
-        e = eps.reshape(len(eps), -1)
-        z = (loc + torch.exp(ls) * e).reshape(eps.shape)
-        return z, -0.5 * self.d * float(np.log(2 * np.pi)) - torch.sum(ls + 0.5 * e * e, 1)
-
-    def _torch_log_prob(self, z, loc, ls):
-        ls = self._ls(ls)
-        v = z.reshape(len(z), -1)
-        return -0.5 * self.d * float(np.log(2 * np.pi)) - torch.sum(ls + 0.5 * ((v - loc) / torch.exp(ls)) ** 2, 1)
+        return _lib.diag_gaussian_log_prob(z, loc, ls, self.temperature, logp=out)

@@ -8,7 +8,7 @@ from torch import nn
 
 from ..base import Flow
 from ..reshape import Split, Merge
-from ... import _lib
+from ... import _lib, autograd
 
 
 def _scale_code(scale, scale_map):
@@ -48,13 +48,17 @@ class AffineConstFlow(Flow):
             raise NotImplementedError("AffineConstFlow kernels cover per-channel parameters ([C] or [C,1,1])")
         return self.s.reshape(c).contiguous(), self.t.reshape(c).contiguous()
 
-    def forward(self, z):
+    def _apply_const(self, z, inverse):
         s, t = self._per_channel(z)
-        return _lib.affine_const(z, s, t, False), self._broadcast_count(z) * torch.sum(self.s)
+        if autograd.needs_grad(z, s, t):
+            return autograd.AffineConstFn.apply(z, s, t, inverse)
+        return _lib.affine_const(z, s, t, inverse)
+
+    def forward(self, z):
+        return self._apply_const(z, False), self._broadcast_count(z) * torch.sum(self.s)
 
     def inverse(self, z):
-        s, t = self._per_channel(z)
-        return _lib.affine_const(z, s, t, True), -self._broadcast_count(z) * torch.sum(self.s)
+        return self._apply_const(z, True), -self._broadcast_count(z) * torch.sum(self.s)
 
 
 class AffineCoupling(Flow):
@@ -72,6 +76,9 @@ class AffineCoupling(Flow):
         z1, z2 = z
         code = _scale_code(self.scale, self.scale_map)
         param = self.param_map(z1)
+        if autograd.needs_grad(z2, param):
+            out, log_det = autograd.AffineCouplingFn.apply(z2, param, 0, z2.shape[1], code, inverse)
+            return [z1, out], (0 if code == _lib.SCALE_NONE else log_det)
         out, log_det = _lib.affine_coupling(z2, param, 0, z2.shape[1], code, inverse)
         if code == _lib.SCALE_NONE:
             # the reference shifts z2 in place and reports the scalar 0 (coupling.py:139-141)
@@ -109,6 +116,8 @@ class MaskedAffineFlow(Flow):
         z_masked = self.b * z
         s = self.s(z_masked) if self.s is not None else None
         t = self.t(z_masked) if self.t is not None else None
+        if autograd.needs_grad(z, s, t):
+            return autograd.MaskedAffineFn.apply(z, s, t, self.b.reshape(-1).contiguous(), inverse)
         return _lib.masked_affine(z, s, t, self.b.reshape(-1).contiguous(), inverse)
 
     def forward(self, z):
@@ -144,6 +153,11 @@ class AffineCouplingBlock(Flow):
         if z.dim() > 2:
             cond_in = cond_in.contiguous()
         param = core.param_map(cond_in)
+        if autograd.needs_grad(z, param, log_q):
+            out, ld = autograd.AffineCouplingFn.apply(z, param, t_off, d_t, code, inverse)
+            if log_q is not None:
+                return out, log_q.add_(ld, alpha=sign)
+            return out, (ld if sign == 1.0 else sign * ld)
         ld = log_q
         if ld is None:
             ld = torch.zeros(z.shape[0], dtype=z.dtype, device=z.device)   # coupling.py:248

@@ -51,11 +51,17 @@ class Permute(Flow):
             self._idx_cache[key] = hit
         return hit
 
+    def _gather(self, z, inverse):
+        if torch.is_grad_enabled() and z.requires_grad:
+            from .. import autograd
+            return autograd.PermuteFn.apply(z, self._idx32(inverse, z.device), self._idx32(not inverse, z.device))
+        return _lib.permute(z, self._idx32(inverse, z.device))
+
     def forward(self, z):
-        return _lib.permute(z, self._idx32(False, z.device)), 0
+        return self._gather(z, False), 0
 
     def inverse(self, z):
-        return _lib.permute(z, self._idx32(True, z.device)), 0
+        return self._gather(z, True), 0
 
 
 class Invertible1x1Conv(Flow):
