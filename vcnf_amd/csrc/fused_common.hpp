@@ -74,9 +74,34 @@ struct RegLogits {
   __device__ __forceinline__ float d(int k) const { return (k == 0 || k == K) ? edge : at(2 * K + k - 1); }
 };
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+constexpr float kLoScale = 2048.f, kLoUnscale = 1.f / 2048.f;
+
+__device__ __forceinline__ floatx4 mfma16h(half8 a, half8 b, floatx4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// hi/lo halves of 4 consecutive accumulator registers (optionally ReLU'd first)
+template <bool RELU>
+__device__ __forceinline__ void split4(const floatx4 v, half4& hi, half4& lo) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    // ReLU and saturation at the fp16 range in one v_med3_f32 (no inf after the conversion)
+    const float x = __builtin_amdgcn_fmed3f(v[r], RELU ? 0.f : -65504.f, 65504.f);
+    const _Float16 hv = (_Float16)x;
+    hi[r] = hv;
+    lo[r] = (_Float16)((x - (float)hv) * kLoScale);
+  }
+}
+
 
 // defined in fused_layer_v2.hip
 int launch_fused_v2_c16(const FusedArgs& a, int inverse, hipStream_t st);
 int launch_fused_v2_c0(const FusedArgs& a, int inverse, hipStream_t st);
+// defined in fused_layer_v3.hip
+int launch_fused_v3_c16(const FusedArgs& a, int inverse, hipStream_t st);
+int launch_fused_v3_c0(const FusedArgs& a, int inverse, hipStream_t st);
 
 }  // namespace vcnf

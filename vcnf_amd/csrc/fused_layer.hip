@@ -313,6 +313,16 @@ extern "C" int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t
   return 0;
 }
 
+// VCNF_FUSED_KERNEL=v2 selects the previous work split of the fp16 split-half kernel (A/B timing).
+static bool use_v2() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VCNF_FUSED_KERNEL");
+    v = (e && e[0] == 'v' && e[1] == '2') ? 1 : 0;
+  }
+  return v == 1;
+}
+
 extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, float* logdet,
                                         int64_t batch, const int32_t* transform_idx, int32_t d_t,
                                         const int32_t* identity_idx, int32_t d_id, int32_t ctx_dim,
@@ -354,10 +364,10 @@ extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, fl
   hipStream_t st = (hipStream_t)stream;
   if (ctx_dim == 16) {
     if (wpack_floats != PackLayout<32, 32, 16, 128, 2, 8>::TOTAL) return VCNF_ERR_SHAPE;
-    if (precision == VCNF_PREC_F16X3) return launch_fused_v2_c16(a, inverse, st);
+    if (precision == VCNF_PREC_F16X3) return use_v2() ? launch_fused_v2_c16(a, inverse, st) : launch_fused_v3_c16(a, inverse, st);
     return launch_fused<32, 32, 16, 128, 2, 8, 2>(a, inverse, st);
   }
   if (wpack_floats != PackLayout<32, 32, 0, 128, 2, 8>::TOTAL) return VCNF_ERR_SHAPE;
-  if (precision == VCNF_PREC_F16X3) return launch_fused_v2_c0(a, inverse, st);
+  if (precision == VCNF_PREC_F16X3) return use_v2() ? launch_fused_v2_c0(a, inverse, st) : launch_fused_v3_c0(a, inverse, st);
   return launch_fused<32, 32, 0, 128, 2, 8, 2>(a, inverse, st);
 }

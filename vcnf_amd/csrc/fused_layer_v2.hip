@@ -32,28 +32,6 @@
 
 namespace vcnf {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-
-constexpr float kLoScale = 2048.f, kLoUnscale = 1.f / 2048.f;
-
-__device__ __forceinline__ floatx4 mfma16h(half8 a, half8 b, floatx4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-
-// hi/lo halves of 4 consecutive accumulator registers (optionally ReLU'd first)
-template <bool RELU>
-__device__ __forceinline__ void split4(const floatx4 v, half4& hi, half4& lo) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    // ReLU and saturation at the fp16 range in one v_med3_f32 (no inf after the conversion)
-    const float x = __builtin_amdgcn_fmed3f(v[r], RELU ? 0.f : -65504.f, 65504.f);
-    const _Float16 hv = (_Float16)x;
-    hi[r] = hv;
-    lo[r] = (_Float16)((x - (float)hv) * kLoScale);
-  }
-}
-
 // NW waves per workgroup (4 or 8).  Trunk: wave w owns hidden row blocks w*RBW .. +RBW-1 for
 // all NW column blocks of the tile; last layer: wave w owns column block w.  Tile = 16*NW
 // samples.  NW = 8: one 512-thread workgroup per CU, every weight byte fetched once per 128
