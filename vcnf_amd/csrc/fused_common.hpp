@@ -96,6 +96,17 @@ __device__ __forceinline__ void split4(const floatx4 v, half4& hi, half4& lo) {
   }
 }
 
+// same with the lower clamp as a run-time value (0: ReLU, -65504: saturation only)
+__device__ __forceinline__ void split4v(const floatx4 v, float lower, half4& hi, half4& lo) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float x = __builtin_amdgcn_fmed3f(v[r], lower, 65504.f);
+    const _Float16 hv = (_Float16)x;
+    hi[r] = hv;
+    lo[r] = (_Float16)((x - (float)hv) * kLoScale);
+  }
+}
+
 
 // defined in fused_layer_v2.hip
 int launch_fused_v2_c16(const FusedArgs& a, int inverse, hipStream_t st);
@@ -103,5 +114,8 @@ int launch_fused_v2_c0(const FusedArgs& a, int inverse, hipStream_t st);
 // defined in fused_layer_v3.hip
 int launch_fused_v3_c16(const FusedArgs& a, int inverse, hipStream_t st);
 int launch_fused_v3_c0(const FusedArgs& a, int inverse, hipStream_t st);
+// defined in fused_layer_v4.hip
+int launch_fused_v4_c16(const FusedArgs& a, int inverse, hipStream_t st);
+int launch_fused_v4_c0(const FusedArgs& a, int inverse, hipStream_t st);
 
 }  // namespace vcnf

@@ -313,14 +313,24 @@ extern "C" int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t
   return 0;
 }
 
-// VCNF_FUSED_KERNEL=v2 selects the previous work split of the fp16 split-half kernel (A/B timing).
-static bool use_v2() {
+// VCNF_FUSED_KERNEL=v2|v3 selects an earlier work split of the fp16 split-half kernel (A/B timing);
+// default: v4 (fused_layer_v4.hip).
+static int fused_version() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("VCNF_FUSED_KERNEL");
-    v = (e && e[0] == 'v' && e[1] == '2') ? 1 : 0;
+    v = (e && e[0] == 'v' && e[1] >= '2' && e[1] <= '4') ? e[1] - '0' : 4;
   }
-  return v == 1;
+  return v;
+}
+
+static int launch_f16x3(const FusedArgs& a, int ctx_dim, int inverse, hipStream_t st) {
+  const int v = fused_version();
+  if (ctx_dim == 16)
+    return v == 2 ? launch_fused_v2_c16(a, inverse, st) : v == 3 ? launch_fused_v3_c16(a, inverse, st)
+                                                                 : launch_fused_v4_c16(a, inverse, st);
+  return v == 2 ? launch_fused_v2_c0(a, inverse, st) : v == 3 ? launch_fused_v3_c0(a, inverse, st)
+                                                               : launch_fused_v4_c0(a, inverse, st);
 }
 
 extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, float* logdet,
@@ -364,10 +374,10 @@ extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, fl
   hipStream_t st = (hipStream_t)stream;
   if (ctx_dim == 16) {
     if (wpack_floats != PackLayout<32, 32, 16, 128, 2, 8>::TOTAL) return VCNF_ERR_SHAPE;
-    if (precision == VCNF_PREC_F16X3) return use_v2() ? launch_fused_v2_c16(a, inverse, st) : launch_fused_v3_c16(a, inverse, st);
+    if (precision == VCNF_PREC_F16X3) return launch_f16x3(a, 16, inverse, st);
     return launch_fused<32, 32, 16, 128, 2, 8, 2>(a, inverse, st);
   }
   if (wpack_floats != PackLayout<32, 32, 0, 128, 2, 8>::TOTAL) return VCNF_ERR_SHAPE;
-  if (precision == VCNF_PREC_F16X3) return use_v2() ? launch_fused_v2_c0(a, inverse, st) : launch_fused_v3_c0(a, inverse, st);
+  if (precision == VCNF_PREC_F16X3) return launch_f16x3(a, 0, inverse, st);
   return launch_fused<32, 32, 0, 128, 2, 8, 2>(a, inverse, st);
 }
