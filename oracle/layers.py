@@ -9,13 +9,14 @@ Restated reference code (paths relative to /root/reference/normflow):
   flows/neural_spline/wrapper.py   CoupledRationalQuadraticSpline :69-75 (direction flip)
   flows/affine/coupling.py         AffineConstFlow :37-53, AffineCoupling :113-168,
       MaskedAffineFlow :202-222, AffineCouplingBlock :247-258
-  flows/reshape.py                 Split / Merge channel modes :25-29, :50-55
-  flows/mixing.py                  Permute :32-54
+  flows/reshape.py                 Split / Merge channel modes :25-29, :50-55, checkerboard :30-42, :56-72
+  flows/mixing.py                  Permute :32-54, LULinearPermute :352-492
   distributions/base.py            DiagGaussian :632-652
   core.py                          NormalizingFlow.log_prob :170-183, .sample :150-155
 """
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from . import rqs, masks
 
@@ -169,22 +170,58 @@ class AffineCoupling:
         return self._apply(z, True)
 
 
+def checker_mask(shape, inv):
+    """reshape.py:30-38: 0/1 colouring of one data point of ``shape`` (no batch dim); an
+    element's colour is the parity of the sum of its indices, 'inv' flips it."""
+    cb0, cb1 = 0, 1
+    for n in reversed(shape):
+        cb0, cb1 = ([cb0 if j % 2 == 0 else cb1 for j in range(n)],
+                    [cb1 if j % 2 == 0 else cb0 for j in range(n)])
+    return torch.tensor(cb1 if inv else cb0)
+
+
+def checker_split(z, inv):
+    """reshape.py:39-42: z1 = the elements coloured 1, z2 = the others, last dim halved."""
+    cb = checker_mask(tuple(z.shape[1:]), inv)[None].repeat(len(z), *((z.dim() - 1) * [1]))
+    size = z.size()
+    z1 = z.reshape(-1)[torch.nonzero(cb.view(-1), as_tuple=False)].view(*size[:-1], -1)
+    z2 = z.reshape(-1)[torch.nonzero((1 - cb).view(-1), as_tuple=False)].view(*size[:-1], -1)
+    return z1, z2
+
+
+def checker_merge(z1, z2, inv):
+    """reshape.py:56-72: both halves repeated along the last dim and blended by the mask."""
+    n = z1.dim()
+    size = list(z1.size())
+    size[-1] *= 2
+    cb = checker_mask(tuple(size[1:]), inv)[None].repeat(size[0], *((n - 1) * [1]))
+    a = z1[..., None].repeat(*(n * [1]), 2).view(*size[:-1], -1)
+    b = z2[..., None].repeat(*(n * [1]), 2).view(*size[:-1], -1)
+    return cb * a + (1 - cb) * b
+
+
 class AffineCouplingBlock:
-    """Split -> AffineCoupling -> Merge (coupling.py:225-258; reshape.py
-    channel / channel_inv modes :25-29, :50-55)."""
+    """Split -> AffineCoupling -> Merge (coupling.py:225-258; reshape.py channel /
+    channel_inv modes :25-29, :50-55; checkerboard modes :30-42, :56-72)."""
 
     def __init__(self, param_fn, scale=True, scale_map="exp", split_mode="channel"):
-        if split_mode not in ("channel", "channel_inv"):
+        if split_mode not in ("channel", "channel_inv", "checkerboard", "checkerboard_inv"):
             raise NotImplementedError("Mode " + split_mode + " is not implemented.")
         self.core = AffineCoupling(param_fn, scale, scale_map)
-        self.flip = split_mode == "channel_inv"
+        self.checker = "checkerboard" in split_mode
+        self.flip = split_mode.endswith("_inv")
 
     def _run(self, z, inverse):
         tot = torch.zeros(z.shape[0], dtype=z.dtype)
-        a, b = z.chunk(2, dim=1)
-        pair = [b, a] if self.flip else [a, b]
+        if self.checker:
+            pair = list(checker_split(z, self.flip))
+        else:
+            a, b = z.chunk(2, dim=1)
+            pair = [b, a] if self.flip else [a, b]
         pair, ld = (self.core.inverse if inverse else self.core.forward)(pair)
         tot += ld
+        if self.checker:
+            return checker_merge(pair[0], pair[1], self.flip), tot
         out = torch.cat([pair[1], pair[0]] if self.flip else pair, 1)
         return out, tot
 
@@ -193,6 +230,39 @@ class AffineCouplingBlock:
 
     def inverse(self, z):
         return self._run(z, True)
+
+
+class LULinearPermute:
+    """mixing.py:352-492: fixed permutation + linear map y = x (L U)^T + bias, L unit lower,
+    diag(U) = softplus(.) + eps.  ``forward`` (sampling direction) = inverse linear map by two
+    triangular solves, then inverse permutation; ``inverse`` = permutation, then the map."""
+
+    def __init__(self, perm, bias, lower_entries, upper_entries, unconstrained_upper_diag, eps=1e-3):
+        d = bias.numel()
+        self.perm, self.bias, self.d = perm, bias, d
+        li, ui = np.tril_indices(d, k=-1), np.triu_indices(d, k=1)
+        diag = F.softplus(unconstrained_upper_diag) + eps                         # :453-455
+        lower = lower_entries.new_zeros(d, d)                                       # :388-399
+        lower[li[0], li[1]] = lower_entries
+        lower[range(d), range(d)] = 1.0
+        upper = upper_entries.new_zeros(d, d)
+        upper[ui[0], ui[1]] = upper_entries
+        upper[range(d), range(d)] = diag
+        self.lower, self.upper = lower, upper
+        self.logabsdet = torch.sum(torch.log(diag))                                 # :457-464
+
+    def forward(self, z):                                                           # :484-487
+        out = z - self.bias                                                         # :420
+        out = torch.linalg.solve_triangular(self.lower, out.t(), upper=False, unitriangular=True)
+        out = torch.linalg.solve_triangular(self.upper, out, upper=True).t()        # :421-423
+        out = out[:, torch.argsort(self.perm)]                                      # :212, :226-229
+        return out, (-self.logabsdet * z.new_ones(z.shape[0])).view(-1)
+
+    def inverse(self, z):                                                           # :489-492
+        out = z[:, self.perm]
+        out = F.linear(out, self.upper)                                             # :409-410
+        out = F.linear(out, self.lower, self.bias)
+        return out, (self.logabsdet * z.new_ones(z.shape[0])).view(-1)
 
 
 class MaskedAffine:

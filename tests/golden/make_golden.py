@@ -514,6 +514,55 @@ def g13_c5_shape():
     save("g13_c5_shape", **out)
 
 
+# ---------------------------------------------------------------- G14
+def g14_lu_linear_permute():
+    """LULinearPermute (mixing.py:352-492): fixed random permutation + LU-parameterised linear map."""
+    out = {}
+    for d in (5, 64):
+        r = rng(1400 + d)
+        x = torch.from_numpy(r.standard_normal((96, d)).astype(np.float32))
+        out["d%d/x" % d] = npy(x)
+        torch.manual_seed(1400 + d)                      # the permutation is drawn with torch.randperm
+        build = lambda: nf.flows.LULinearPermute(d, identity_init=False)
+        state = {}
+
+        def build_fixed():
+            m = build()
+            if "perm" in state:
+                m.permutation._permutation.copy_(state["perm"])
+            else:
+                state["perm"] = m.permutation._permutation.clone()
+            return m
+        call = lambda m, a: m.forward(a) + m.inverse(a)
+        ents, ints, o32, o64, _ = run_module_case(build_fixed, 1401 + d, [x], call, weight_gain=0.5)
+        pack(out, "d%d" % d, ents, ints, ["fwd_z", "fwd_ld", "inv_z", "inv_ld"], o32, o64)
+    save("g14_lu_linear_permute", **out)
+
+
+# ---------------------------------------------------------------- G15 (SURVEY 8f row 2)
+def g15_checkerboard():
+    """Checkerboard Split / Merge (reshape.py:30-44, :56-72) on 2-D, 3-D and 4-D inputs, and an
+    AffineCouplingBlock over a checkerboard split of [B, D] inputs."""
+    out = {}
+    r = rng(1500)
+    for name, shape in (("2d", (7, 10)), ("3d", (5, 3, 6)), ("4d", (4, 3, 5, 8))):
+        z = torch.from_numpy(r.standard_normal(shape).astype(np.float32))
+        out[name + "/z"] = npy(z)
+        for mode in ("checkerboard", "checkerboard_inv"):
+            (z1, z2), _ = nf.flows.Split(mode).forward(z)
+            back, _ = nf.flows.Merge(mode).forward([z1, z2])
+            assert torch.equal(back, z)
+            out["%s/%s/z1" % (name, mode)], out["%s/%s/z2" % (name, mode)] = npy(z1), npy(z2)
+    x = torch.from_numpy(r.standard_normal((64, 12)).astype(np.float32))
+    out["blk/x"] = npy(x)
+    for mode in ("checkerboard", "checkerboard_inv"):
+        build = lambda: nf.flows.AffineCouplingBlock(nf.nets.MLP([6, 16, 12], init_zeros=False), split_mode=mode)
+        call = lambda m, a: m.forward(a.clone()) + m.inverse(a.clone())
+        ents, ints, o32, o64, _ = run_module_case(build, 1501, [x], call)
+        pack(out, "blk/" + mode, ents, ints, ["fwd_z", "fwd_ld", "inv_z", "inv_ld"], o32, o64)
+    save("g15_checkerboard", **out)
+
+
 if __name__ == "__main__":
     g1_rqs()
     g2_tails()
@@ -528,3 +577,5 @@ if __name__ == "__main__":
     g11_glow_multiscale()
     g12_c2_tabular()
     g13_c5_shape()
+    g14_lu_linear_permute()
+    g15_checkerboard()

@@ -312,3 +312,46 @@ def test_reverse_kld_and_alpha_div(hip):
         assert torch.isfinite(loss)
     out = model.forward_kld(torch.randn(64, 2, device="cuda"), extended=True)
     assert len(out) == 4 and len(out[1]) == len(model.flows) and out[3].shape == (64,)
+
+
+def test_nsf_stack_with_lu_linear_permute_trains(hip):
+    """The neural-spline-flow layout of arXiv 1906.04032 (spline coupling + LULinearPermute per
+    layer): gradients against the oracle stack in fp64, then a few optimiser steps."""
+    from oracle import layers as OL
+    from helpers import oracle_rqs_coupling
+    torch.manual_seed(11)
+    d, layers, hidden, k = 8, 2, 32, 6
+    flows = []
+    for i in range(layers):
+        flows += [nf.flows.CoupledRationalQuadraticSpline(d, 1, hidden, k, reverse_mask=bool(i % 2)),
+                  nf.flows.LULinearPermute(d, identity_init=False)]
+    model = nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows)
+    with torch.no_grad():                            # non-trivial conditioner outputs
+        for n, p in model.named_parameters():
+            if "final_layer" in n:
+                p.normal_(0, 0.3)
+    sd = {n: v.detach().clone() for n, v in model.state_dict().items()}
+    model = model.to("cuda")
+    x = torch.randn(256, d)
+
+    def ora(s, xx):
+        fl = []
+        for i in range(layers):
+            fl.append(oracle_rqs_coupling(s, "flows.%d.prqct." % (2 * i), k, 3.0, hidden))
+            pre = "flows.%d." % (2 * i + 1)
+            fl.append(OL.LULinearPermute(s[pre + "permutation._permutation"], s[pre + "linear.bias"],
+                                         s[pre + "linear.lower_entries"], s[pre + "linear.upper_entries"],
+                                         s[pre + "linear.unconstrained_upper_diag"]))
+        return OL.Stack(OL.DiagGaussian(s["q0.loc"], s["q0.log_scale"]), fl).log_prob(xx)
+    _grad_compare(model.log_prob, ora, sd, [x], "nsf log_prob")
+    opt = torch.optim.Adam(model.parameters(), lr=3e-3)
+    xs = dev(x) * 0.5 + 1.0
+    first = last = None
+    for _ in range(15):
+        opt.zero_grad()
+        loss = model.forward_kld(xs)
+        loss.backward()
+        opt.step()
+        first = float(loss.detach()) if first is None else first
+        last = float(loss.detach())
+    assert np.isfinite(last) and last < first - 0.3, (first, last)

@@ -703,3 +703,40 @@ def test_actnorm_data_dependent_init(hip):
         xr, ldi = a.inverse(y)
         assert_close(xr, x.cpu(), rtol=1e-5, atol=1e-5, what="round trip")
         assert_close(ld + ldi, torch.zeros(()), rtol=0, atol=1e-4, what="log-det cancel")
+
+
+# ---------------------------------------------------------------- next rows: LULinearPermute (G14), checkerboard (G15)
+@pytest.mark.parametrize("d", [5, 64])
+def test_g14_lu_linear_permute(hip, d):
+    fx = fixture("g14_lu_linear_permute")
+    tag = "d%d" % d
+    sd, _ = state_for(fx, tag, 1401 + d, weight_gain=0.5)
+    lay = load(nf.flows.LULinearPermute(d, identity_init=False), sd)
+    x = dev(T(fx[tag + "/x"]))
+    with torch.no_grad():
+        for dirn, fn in (("fwd", lay.forward), ("inv", lay.inverse)):
+            z, ld = fn(x)
+            parity(z, fx["%s/%s_z32" % (tag, dirn)], fx["%s/%s_z64" % (tag, dirn)], rtol=1e-5, atol=1e-5, what=dirn + " z")
+            assert_close(ld, fx["%s/%s_ld32" % (tag, dirn)], what=dirn + " ld", rtol=1e-6, atol=1e-6)
+        # the stand-alone permutation module is the HIP column gather
+        p, _ = lay.permutation(x)
+        assert torch.equal(p.cpu(), x.cpu()[:, lay.permutation._permutation.cpu()])
+        back, _ = lay.permutation.inverse(p)
+        assert torch.equal(back, x)
+
+
+@pytest.mark.parametrize("mode", ["checkerboard", "checkerboard_inv"])
+def test_g15_checkerboard_affine_block(hip, mode):
+    fx = fixture("g15_checkerboard")
+    sd, _ = state_for(fx, "blk/" + mode, 1501)
+    blk = load(nf.flows.AffineCouplingBlock(nf.nets.MLP([6, 16, 12]), split_mode=mode), sd)
+    x = dev(T(fx["blk/x"]))
+    with torch.no_grad():
+        for dirn, fn in (("fwd", blk.forward), ("inv", blk.inverse)):
+            z, ld = fn(x.clone())
+            assert_close(z, fx["blk/%s/%s_z32" % (mode, dirn)], what=dirn + " z", **TOL)
+            assert_close(ld, fx["blk/%s/%s_ld32" % (mode, dirn)], what=dirn + " ld", **TOL)
+        z4 = dev(T(fx["4d/z"]))
+        (a, b), _ = nf.flows.Split(mode).forward(z4)
+        assert np.array_equal(a.cpu().numpy(), fx["4d/%s/z1" % mode])
+        assert np.array_equal(b.cpu().numpy(), fx["4d/%s/z2" % mode])

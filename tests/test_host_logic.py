@@ -194,3 +194,48 @@ def test_shard_bounds_partition():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         nf.shard_bounds(8, 2, 2)
+
+
+# ---------------------------------------------------------------- next rows built from tensor ops
+def test_checkerboard_split_merge_matches_reference_fixture():
+    import vcnf_amd as nf
+    from helpers import fixture, T
+    fx = fixture("g15_checkerboard")
+    for name in ("2d", "3d", "4d"):
+        z = T(fx[name + "/z"])
+        for mode in ("checkerboard", "checkerboard_inv"):
+            (z1, z2), ld = nf.flows.Split(mode).forward(z)
+            assert ld == 0
+            assert np.array_equal(z1.numpy(), fx["%s/%s/z1" % (name, mode)])
+            assert np.array_equal(z2.numpy(), fx["%s/%s/z2" % (name, mode)])
+            back, _ = nf.flows.Merge(mode).forward([z1, z2])
+            assert torch.equal(back, z)
+            again, _ = nf.flows.Split(mode).inverse([z1, z2])
+            assert torch.equal(again, z)
+    with pytest.raises(ValueError):
+        nf.flows.Split("checkerboard").forward(torch.zeros(2, 5))
+
+
+@pytest.mark.parametrize("d", [5, 64])
+def test_lu_linear_permute_matches_reference_fixture(d):
+    """One GEMM per direction (permutation folded into L U / its fp64 inverse) against the
+    reference's two triangular products / solves + index_select."""
+    import vcnf_amd as nf
+    from helpers import fixture, T, state_for, assert_close
+    fx = fixture("g14_lu_linear_permute")
+    tag = "d%d" % d
+    sd, _ = state_for(fx, tag, 1401 + d, weight_gain=0.5)
+    lay = nf.flows.LULinearPermute(d, identity_init=False)
+    lay.load_state_dict(sd)
+    x = T(fx[tag + "/x"])
+    with torch.no_grad():
+        for dirn, fn in (("fwd", lay.forward), ("inv", lay.inverse)):
+            z, ld = fn(x)
+            # noise of the reference's own fp32 run on this fixture bounds the comparison
+            noise = float(np.abs(fx["%s/%s_z32" % (tag, dirn)] - fx["%s/%s_z64" % (tag, dirn)]).max())
+            assert_close(z, fx["%s/%s_z64" % (tag, dirn)], what=dirn + " z", rtol=1e-5, atol=1e-5 + 4 * noise)
+            assert_close(ld, fx["%s/%s_ld32" % (tag, dirn)], what=dirn + " ld", rtol=1e-6, atol=1e-6)
+        assert lay.linear._mats, "matrices are cached when no gradient is required"
+    z, ld = lay.inverse(x.clone().requires_grad_())
+    (z.sum() + ld.sum()).backward()
+    assert all(p.grad is not None for p in lay.parameters())

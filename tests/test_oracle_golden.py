@@ -225,3 +225,42 @@ def test_g11_glow_multiscale():
         z, lq = ms.sample_from([T(fx["eps0"], dt), T(fx["eps1"], dt)])
         assert_close(z, fx["glow/s_z" + suf], what="sample z", **tol)
         assert_close(lq, fx["glow/s_logq" + suf], what="sample log_q", **tol)
+
+
+# ---------------------------------------------------------------- next rows
+@pytest.mark.parametrize("d", [5, 64])
+def test_g14_lu_linear_permute(d):
+    fx = fixture("g14_lu_linear_permute")
+    tag = "d%d" % d
+    for dt, suf, tol in ((torch.float32, "32", dict(rtol=2e-4, atol=2e-4)), (torch.float64, "64", F64)):
+        sd, _ = state_for(fx, tag, 1401 + d, dt, weight_gain=0.5)
+        lay = OL.LULinearPermute(sd["permutation._permutation"], sd["linear.bias"], sd["linear.lower_entries"],
+                                 sd["linear.upper_entries"], sd["linear.unconstrained_upper_diag"])
+        x = T(fx[tag + "/x"], dt)
+        for dirn, fn in (("fwd", lay.forward), ("inv", lay.inverse)):
+            z, ld = fn(x)
+            assert_close(z, fx["%s/%s_z%s" % (tag, dirn, suf)], what=dirn + " z", **tol)
+            assert_close(ld, fx["%s/%s_ld%s" % (tag, dirn, suf)], what=dirn + " ld", **tol)
+        back, _ = lay.inverse(lay.forward(x)[0])
+        assert_close(back, x, what="round trip", rtol=1e-3 if dt == torch.float32 else 1e-9,
+                     atol=1e-3 if dt == torch.float32 else 1e-9)
+
+
+@pytest.mark.parametrize("mode", ["checkerboard", "checkerboard_inv"])
+def test_g15_checkerboard(mode):
+    fx = fixture("g15_checkerboard")
+    inv = mode.endswith("inv")
+    for name in ("2d", "3d", "4d"):
+        z = T(fx[name + "/z"])
+        z1, z2 = OL.checker_split(z, inv)
+        assert np.array_equal(z1.numpy(), fx["%s/%s/z1" % (name, mode)])
+        assert np.array_equal(z2.numpy(), fx["%s/%s/z2" % (name, mode)])
+        assert torch.equal(OL.checker_merge(z1, z2, inv), z)
+    for dt, suf, tol in ((torch.float32, "32", F32), (torch.float64, "64", F64)):
+        sd, _ = state_for(fx, "blk/" + mode, 1501, dt)
+        blk = OL.AffineCouplingBlock(lambda z: ON.mlp(sd, "flows.1.param_map.", z), split_mode=mode)
+        x = T(fx["blk/x"], dt)
+        for dirn, fn in (("fwd", blk.forward), ("inv", blk.inverse)):
+            z, ld = fn(x.clone())
+            assert_close(z, fx["blk/%s/%s_z%s" % (mode, dirn, suf)], what=dirn + " z", **tol)
+            assert_close(ld, fx["blk/%s/%s_ld%s" % (mode, dirn, suf)], what=dirn + " ld", **tol)

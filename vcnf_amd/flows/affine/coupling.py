@@ -141,7 +141,15 @@ class AffineCouplingBlock(Flow):
 
     def _run(self, z, inverse, log_q=None, sign=1.0):
         if self.split_mode not in ('channel', 'channel_inv'):
-            raise NotImplementedError('Mode ' + self.split_mode + ' is not built yet (SURVEY 8f row 2).')
+            # checkerboard: explicit Split -> AffineCoupling (pair form of the kernel) -> Merge
+            pair, _ = (self.flows[0].forward(z) if not inverse else self.flows[2].inverse(z))
+            pair, ld = (self.flows[1].forward(pair) if not inverse else self.flows[1].inverse(pair))
+            out, _ = (self.flows[2].forward(pair) if not inverse else self.flows[0].inverse(pair))
+            if not torch.is_tensor(ld):
+                ld = torch.zeros(z.shape[0], dtype=z.dtype, device=z.device)
+            if log_q is not None:
+                return out, log_q.add_(ld, alpha=sign)
+            return out, (ld if sign == 1.0 else sign * ld)
         core = self.flows[1]
         code = _scale_code(core.scale, core.scale_map)
         c = z.shape[1]

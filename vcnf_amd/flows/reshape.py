@@ -1,13 +1,34 @@
 """Split / Merge / Squeeze.  In the fused coupling blocks the channel split and
 merge are pure addressing inside the HIP kernel; these modules exist for the
 reference's composition API (list-of-two-tensors convention) and are views plus
-one concatenation.  Checkerboard modes are a "next" row.
+one concatenation; the checkerboard modes are an index gather / scatter along the last
+dimension.
 Reference: normflow/flows/reshape.py:9-116."""
 import torch
 
 from .base import Flow
 
 _CHANNEL_MODES = ('channel', 'channel_inv')
+_CHECKER_MODES = ('checkerboard', 'checkerboard_inv')
+
+
+def _checker_index(shape, inv, device):
+    """Last-dimension positions of the two colours for one data point of ``shape`` (without
+    batch): colour of an element = parity of the sum of its indices (reshape.py:30-38); z1
+    takes the odd-parity elements ('checkerboard') or the even ones ('checkerboard_inv').
+    Returns (idx1, idx2), each [*shape[:-1], shape[-1] // 2] int64."""
+    if shape[-1] % 2:
+        raise ValueError("checkerboard split needs an even last dimension")
+    lead = torch.zeros(shape[:-1], dtype=torch.int64, device=device)
+    for ax, n in enumerate(shape[:-1]):
+        view = [1] * (len(shape) - 1)
+        view[ax] = n
+        lead = lead + torch.arange(n, device=device).view(view)
+    lead = (lead % 2)[..., None]                                 # parity of the leading indices
+    half = 2 * torch.arange(shape[-1] // 2, device=device)
+    odd = half + (1 - lead)                                      # positions with odd total parity
+    even = half + lead
+    return (even, odd) if inv else (odd, even)
 
 
 class Split(Flow):
@@ -16,13 +37,15 @@ class Split(Flow):
         self.mode = mode
 
     def _check(self):
-        if self.mode not in _CHANNEL_MODES:
-            if 'checkerboard' in self.mode:
-                raise NotImplementedError('Mode ' + self.mode + ' is not built yet (SURVEY 8f row 2).')
+        if self.mode not in _CHANNEL_MODES + _CHECKER_MODES:
             raise NotImplementedError('Mode ' + self.mode + ' is not implemented.')
 
     def forward(self, z):
         self._check()
+        if self.mode in _CHECKER_MODES:
+            i1, i2 = _checker_index(tuple(z.shape[1:]), self.mode.endswith('inv'), z.device)
+            b = z.shape[0]
+            return [torch.gather(z, -1, i1.expand(b, *i1.shape)), torch.gather(z, -1, i2.expand(b, *i2.shape))], 0
         first, second = z.chunk(2, dim=1)           # first chunk takes ceil(C/2) channels
         pair = [second, first] if self.mode == 'channel_inv' else [first, second]
         return pair, 0
@@ -30,6 +53,13 @@ class Split(Flow):
     def inverse(self, z):
         self._check()
         z1, z2 = z
+        if self.mode in _CHECKER_MODES:
+            shape = tuple(z1.shape[1:-1]) + (2 * z1.shape[-1],)
+            i1, i2 = _checker_index(shape, self.mode.endswith('inv'), z1.device)
+            b = z1.shape[0]
+            out = z1.new_empty((b,) + shape)
+            out = out.scatter(-1, i1.expand(b, *i1.shape), z1).scatter(-1, i2.expand(b, *i2.shape), z2)
+            return out, 0
         return torch.cat([z2, z1] if self.mode == 'channel_inv' else [z1, z2], 1), 0
 
 
