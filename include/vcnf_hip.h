@@ -44,7 +44,7 @@ enum {
 };
 
 enum { VCNF_LD_STORE = 0, VCNF_LD_ACCUM = 1 };
-enum { VCNF_TAILS_NONE = 0, VCNF_TAILS_LINEAR = 1 };
+enum { VCNF_TAILS_NONE = 0, VCNF_TAILS_LINEAR = 1, VCNF_TAILS_CIRCULAR = 2 };
 enum { VCNF_PREC_F32 = 0, VCNF_PREC_F16X3 = 1 };   /* matrix path of the fused layer kernel */
 enum { VCNF_SCALE_EXP = 0, VCNF_SCALE_SIGMOID = 1, VCNF_SCALE_SIGMOID_INV = 2, VCNF_SCALE_NONE = 3 };
 
@@ -56,7 +56,8 @@ const char* vcnf_status_string(int status);
  * (normflow/utils/splines.py:20-29, :88-96). */
 typedef struct vcnf_rqs_cfg {
   int32_t num_bins;        /* K */
-  int32_t tails;           /* VCNF_TAILS_* ; LINEAR: K-1 derivative logits, identity outside */
+  int32_t tails;           /* VCNF_TAILS_* ; LINEAR: K-1 derivative logits, identity outside;
+                              CIRCULAR: K logits (last knot = first knot, splines.py:44-49), identity outside */
   float left, right;       /* x interval; LINEAR uses [-tail_bound, tail_bound] */
   float bottom, top;       /* y interval */
   float min_bin_width;     /* splines.py:6 */

@@ -159,7 +159,7 @@ def g3_crqs_layer():
     save("g3_crqs_layer", **out)
 
 
-def cond_prqc(features, ctx, hidden, blocks, k, tb, even, mask_kind="alt"):
+def cond_prqc(features, ctx, hidden, blocks, k, tb, even, mask_kind="alt", tails="linear"):
     def net(i, o):
         return ResidualNet(in_features=i, out_features=o, hidden_features=hidden,
                            context_features=ctx, num_blocks=blocks,
@@ -170,7 +170,7 @@ def cond_prqc(features, ctx, hidden, blocks, k, tb, even, mask_kind="alt"):
     else:
         mask = ref_masks.create_mid_split_binary_mask(features)
     return PiecewiseRationalQuadraticCoupling(mask=mask, transform_net_create_fn=net, num_bins=k,
-                                              tails="linear", tail_bound=tb,
+                                              tails=tails, tail_bound=tb,
                                               apply_unconditional_transform=True)
 
 
@@ -563,6 +563,39 @@ def g15_checkerboard():
     save("g15_checkerboard", **out)
 
 
+# ---------------------------------------------------------------- G16
+def g16_circular():
+    """Circular tails (splines.py:44-49: K derivative logits, last knot = first knot): the
+    functional spline and a conditional coupling layer with its unconditional transform."""
+    out = {}
+    for k, tb in ((8, 3.0), (5, 2.5)):
+        r = rng(1600 + k)
+        x = (2.0 * r.standard_normal((256, 10))).astype(np.float32)
+        x[0, :6] = np.array([tb, -tb, np.nextafter(np.float32(tb), np.float32(100)), 0.0, 50.0, -1e5], dtype=np.float32)
+        x = torch.from_numpy(x)
+        uw, uh, ud = (torch.from_numpy(r.standard_normal((256, 10, k)).astype(np.float32)) for _ in range(3))
+        tag0 = "K%d_T%g" % (k, tb)
+        for inv in (False, True):
+            f = lambda a, b, c, d: ref_splines.unconstrained_rational_quadratic_spline(
+                a, b, c, d, inverse=inv, tails="circular", tail_bound=tb)
+            (y32, l32), (y64, l64) = both(f, x, uw, uh, ud)
+            tag = tag0 + ("_inv" if inv else "_fwd")
+            out[tag + "/y32"], out[tag + "/ld32"] = npy(y32), npy(l32)
+            out[tag + "/y64"], out[tag + "/ld64"] = npy(y64), npy(l64)
+        out[tag0 + "/x"], out[tag0 + "/uw"] = npy(x), npy(uw)
+        out[tag0 + "/uh"], out[tag0 + "/ud"] = npy(uh), npy(ud)
+    d, c, h, nb, k, tb = 12, 4, 32, 1, 6, 2.0
+    r = rng(1650)
+    x = torch.from_numpy((1.3 * r.standard_normal((256, d))).astype(np.float32))
+    ctx = torch.from_numpy(r.standard_normal((256, c)).astype(np.float32))
+    build = lambda: cond_prqc(d, c, h, nb, k, tb, even=False, tails="circular")
+    call = lambda m, a, b: m.forward(a, b) + m.inverse(a, b)
+    ents, ints, o32, o64, _ = run_module_case(build, 1651, [x, ctx], call, final_gain=2.0)
+    pack(out, "layer", ents, ints, ["nsf_fwd_z", "nsf_fwd_ld", "nsf_inv_z", "nsf_inv_ld"], o32, o64)
+    out["layer/x"], out["layer/ctx"] = npy(x), npy(ctx)
+    save("g16_circular", **out)
+
+
 if __name__ == "__main__":
     g1_rqs()
     g2_tails()
@@ -579,3 +612,4 @@ if __name__ == "__main__":
     g13_c5_shape()
     g14_lu_linear_permute()
     g15_checkerboard()
+    g16_circular()

@@ -47,14 +47,14 @@ def close(got, want, what, want32=None, rtol=2e-3, atol=2e-4):
         what, int(bad.sum()), bad.numel(), float(err.max()), scale)
 
 
-@pytest.mark.parametrize("tails", ["linear", None])
+@pytest.mark.parametrize("tails", ["linear", None, "circular"])
 @pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("k", [8, 5, 16])
 def test_spline_vjp_vs_oracle_autograd(hip, tails, inverse, k):
     g = torch.Generator().manual_seed(100 + k)
     n, bound = 20000, 3.0
-    nd = k - 1 if tails == "linear" else k + 1
-    if tails == "linear":
+    nd = k - 1 if tails == "linear" else k if tails == "circular" else k + 1
+    if tails is not None:
         x = (torch.rand(n, generator=g) * 2 - 1) * bound * 1.2          # includes the tails
     else:
         x = torch.rand(n, generator=g) * 0.998 + 0.001
@@ -63,19 +63,20 @@ def test_spline_vjp_vs_oracle_autograd(hip, tails, inverse, k):
 
     def oracle_grads(dtype):
         leaves = [t.clone().to(dtype).requires_grad_() for t in (x, uw, uh, ud)]
-        if tails == "linear":
-            y, lad = orqs.rq_spline_tails(*leaves, inverse=inverse, tails="linear", tail_bound=bound)
+        if tails is not None:
+            y, lad = orqs.rq_spline_tails(*leaves, inverse=inverse, tails=tails, tail_bound=bound)
         else:
             y, lad = orqs.rq_spline(*leaves, inverse=inverse)
         return y, torch.autograd.grad([y, lad], leaves, [gy.to(dtype), gl.to(dtype)])
     y, want = oracle_grads(torch.float64)
-    _, want32 = oracle_grads(torch.float32)
+    y32, want32 = oracle_grads(torch.float32)
 
     cfg = _lib.make_cfg(k, tails, tail_bound=bound if tails else 1.0)
     dl = [dev(t).requires_grad_() for t in (x, uw, uh, ud)]
     yy, ll = vag.rqs_spline(*dl, cfg, inverse=inverse)
     got = torch.autograd.grad([yy, ll], dl, [dev(gy), dev(gl)])
-    assert torch.allclose(yy.cpu().double(), y.detach(), rtol=1e-4, atol=1e-4)
+    noise = float((y32.detach().double() - y.detach()).abs().max())      # the oracle's own fp32 error
+    assert float((yy.detach().cpu().double() - y.detach()).abs().max()) <= 1e-4 + 8 * noise
     for a, b, b32, nm in zip(got, want, want32, ("g_x", "g_uw", "g_uh", "g_ud")):
         close(a, b, "%s tails=%s inverse=%s K=%d" % (nm, tails, inverse, k), want32=b32)
 

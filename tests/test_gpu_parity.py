@@ -740,3 +740,38 @@ def test_g15_checkerboard_affine_block(hip, mode):
         (a, b), _ = nf.flows.Split(mode).forward(z4)
         assert np.array_equal(a.cpu().numpy(), fx["4d/%s/z1" % mode])
         assert np.array_equal(b.cpu().numpy(), fx["4d/%s/z2" % mode])
+
+
+# ---------------------------------------------------------------- next row: circular tails (G16)
+@pytest.mark.parametrize("case", ["K8_T3", "K5_T2.5"])
+@pytest.mark.parametrize("inv", [False, True])
+def test_g16_circular_tails_functional(hip, case, inv):
+    fx = fixture("g16_circular")
+    tb = float(case.split("_T")[1])
+    tag = case + ("_inv" if inv else "_fwd")
+    args = [dev(T(fx["%s/%s" % (case, n)])) for n in ("x", "uw", "uh", "ud")]
+    with torch.no_grad():
+        y, ld = nf.utils.splines.unconstrained_rational_quadratic_spline(*args, inverse=inv, tails="circular",
+                                                                         tail_bound=tb)
+    parity(y, fx[tag + "/y32"], fx[tag + "/y64"], what="y")
+    parity(ld, fx[tag + "/ld32"], fx[tag + "/ld64"], what="ld")
+    nf.check_discriminant()
+
+
+def test_g16_circular_coupling_layer(hip):
+    fx = fixture("g16_circular")
+    sd, _ = state_for(fx, "layer", 1651, final_gain=2.0)
+    net = lambda i, o: nf.nets.ResidualNet(in_features=i, out_features=o, hidden_features=32, context_features=4,
+                                           num_blocks=1, activation=torch.nn.functional.relu,
+                                           dropout_probability=0.0, use_batch_norm=False)
+    m = nf.flows.neural_spline.coupling.PiecewiseRationalQuadraticCoupling(
+        mask=nf.utils.masks.create_alternating_binary_mask(12, even=False), transform_net_create_fn=net,
+        num_bins=6, tails="circular", tail_bound=2.0, apply_unconditional_transform=True)
+    m = load(m, sd)
+    x, ctx = dev(T(fx["layer/x"])), dev(T(fx["layer/ctx"]))
+    with torch.no_grad():
+        for dirn, fn in (("nsf_fwd", m.forward), ("nsf_inv", m.inverse)):
+            z, ld = fn(x, ctx)
+            parity(z, fx["layer/%s_z32" % dirn], fx["layer/%s_z64" % dirn], what=dirn + " z")
+            parity(ld, fx["layer/%s_ld32" % dirn], fx["layer/%s_ld64" % dirn], what=dirn + " ld")
+    nf.check_discriminant()

@@ -264,3 +264,28 @@ def test_g15_checkerboard(mode):
             z, ld = fn(x.clone())
             assert_close(z, fx["blk/%s/%s_z%s" % (mode, dirn, suf)], what=dirn + " z", **tol)
             assert_close(ld, fx["blk/%s/%s_ld%s" % (mode, dirn, suf)], what=dirn + " ld", **tol)
+
+
+@pytest.mark.parametrize("case", ["K8_T3", "K5_T2.5"])
+@pytest.mark.parametrize("inv", [False, True])
+def test_g16_circular_tails(case, inv):
+    fx = fixture("g16_circular")
+    tb = float(case.split("_T")[1])
+    tag = case + ("_inv" if inv else "_fwd")
+    for dt, suf, tol in ((torch.float32, "32", F32), (torch.float64, "64", F64)):
+        args = [T(fx["%s/%s" % (case, n)], dt) for n in ("x", "uw", "uh", "ud")]
+        y, ld = OR.rq_spline_tails(*args, inverse=inv, tails="circular", tail_bound=tb)
+        assert_close(y, fx[tag + "/y" + suf], what="y", **tol)
+        assert_close(ld, fx[tag + "/ld" + suf], what="ld", **tol)
+
+
+def test_g16_circular_coupling_layer():
+    fx = fixture("g16_circular")
+    for dt, suf, tol in ((torch.float32, "32", dict(rtol=2e-5, atol=2e-5)), (torch.float64, "64", F64)):
+        sd, _ = state_for(fx, "layer", 1651, dt, final_gain=2.0)
+        lay = oracle_rqs_coupling(sd, "", 6, 2.0, 32, tails="circular")
+        x, ctx = T(fx["layer/x"], dt), T(fx["layer/ctx"], dt)
+        for dirn, fn in (("nsf_fwd", lay.nsf_forward), ("nsf_inv", lay.nsf_inverse)):
+            z, ld = fn(x, ctx)
+            assert_close(z, fx["layer/%s_z%s" % (dirn, suf)], what=dirn + " z", **tol)
+            assert_close(ld, fx["layer/%s_ld%s" % (dirn, suf)], what=dirn + " ld", **tol)

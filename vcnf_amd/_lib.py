@@ -18,7 +18,7 @@ _I32, _I64, _F32, _INT = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.
 
 OK = 0
 LD_STORE, LD_ACCUM = 0, 1
-TAILS_NONE, TAILS_LINEAR = 0, 1
+TAILS_NONE, TAILS_LINEAR, TAILS_CIRCULAR = 0, 1, 2
 SCALE_EXP, SCALE_SIGMOID, SCALE_SIGMOID_INV, SCALE_NONE = 0, 1, 2, 3
 SCALE_MAPS = {"exp": SCALE_EXP, "sigmoid": SCALE_SIGMOID, "sigmoid_inv": SCALE_SIGMOID_INV}
 
@@ -130,15 +130,24 @@ def require_device(*tensors, allow_grad=False):
     return dev
 
 
+def n_derivatives(cfg):
+    """Derivative logits per element: K-1 (linear tails), K (circular), K+1 (no tails)."""
+    k = cfg.num_bins
+    return k - 1 if cfg.tails == TAILS_LINEAR else k if cfg.tails == TAILS_CIRCULAR else k + 1
+
+
 def make_cfg(num_bins, tails, tail_bound=1.0, left=0.0, right=1.0, bottom=0.0, top=1.0,
              min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, wh_scale=1.0):
     if tails == "linear":
         left, right, bottom, top = -tail_bound, tail_bound, -tail_bound, tail_bound
         mode = TAILS_LINEAR
+    elif tails == "circular":
+        left, right, bottom, top = -tail_bound, tail_bound, -tail_bound, tail_bound
+        mode = TAILS_CIRCULAR
     elif tails is None:
         mode = TAILS_NONE
     else:
-        # circular tails / per-feature tail lists: SURVEY 8f row 4, not built
+        # per-feature tail lists: SURVEY 8f row 4, not built
         raise RuntimeError("{} tails are not implemented.".format(tails))
     return RqsCfg(int(num_bins), mode, float(left), float(right), float(bottom), float(top),
                   float(min_bin_width), float(min_bin_height), float(min_derivative), float(wh_scale))
@@ -175,7 +184,7 @@ def rqs_elementwise(x, uw, uh, ud, cfg, inverse, allow_grad=False):
     dev = require_device(x, uw, uh, ud, allow_grad=allow_grad)
     shape = x.shape
     k = cfg.num_bins
-    nd = k - 1 if cfg.tails == TAILS_LINEAR else k + 1
+    nd = n_derivatives(cfg)
     if uw.shape != shape + (k,) or uh.shape != shape + (k,) or ud.shape != shape + (nd,):
         raise VcnfError("spline parameter shapes %s %s %s do not match inputs %s with K=%d" % (
             tuple(uw.shape), tuple(uh.shape), tuple(ud.shape), tuple(shape), k))
@@ -204,7 +213,7 @@ def rqs_elementwise_bwd(x, uw, uh, ud, gy, glad, cfg, inverse):
     """VJP of rqs_elementwise: returns (g_x, g_uw, g_uh, g_ud), shapes of the inputs."""
     dev = require_device(x, uw, uh, ud, gy, glad, allow_grad=True)
     k = cfg.num_bins
-    nd = k - 1 if cfg.tails == TAILS_LINEAR else k + 1
+    nd = n_derivatives(cfg)
     shape = x.shape
     xf = x.detach().reshape(-1).contiguous()
     w2 = uw.detach().reshape(-1, k).contiguous()

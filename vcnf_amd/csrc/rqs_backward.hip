@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kBwdBlock) void rqs_elementwise_bwd_kernel(const Bw
     float* guw = a.guw + i * K;
     float* guh = a.guh + i * K;
     float* gud = a.gud + i * a.nd;
-    if (c.tails == 1 && !((x >= c.lo_x) && (x <= c.hi_x))) {     // identity outside: dy/dx = 1
+    if (c.tails != 0 && !((x >= c.lo_x) && (x <= c.hi_x))) {     // identity outside: dy/dx = 1
       a.gx[i] = gy;
       for (int k = 0; k < K; ++k) { guw[k] = 0.f; guh[k] = 0.f; }
       for (int k = 0; k < a.nd; ++k) gud[k] = 0.f;
@@ -180,7 +180,8 @@ __global__ __launch_bounds__(kBwdBlock) void rqs_elementwise_bwd_kernel(const Bw
     }
     // knot derivatives of the bin: logit index (or boundary constant)
     const int i0 = c.tails == 1 ? bin - 1 : bin;            // logit of the left knot (-1: boundary)
-    const int i1 = c.tails == 1 ? bin : bin + 1;            // logit of the right knot (nd: boundary)
+    // logit of the right knot (linear: nd = boundary constant; circular: knot K shares logit 0)
+    const int i1 = c.tails == 1 ? bin : (c.tails == 2 && bin + 1 == K) ? 0 : bin + 1;
     const bool has0 = i0 >= 0, has1 = i1 < a.nd;
     const float l0 = has0 ? ud[i0] : c.edge_logit, l1 = has1 ? ud[i1] : c.edge_logit;
     b.d0 = c.min_d + softplus_f(l0);
@@ -220,8 +221,8 @@ __global__ __launch_bounds__(kBwdBlock) void rqs_elementwise_bwd_kernel(const Bw
       guh[k] = c.wh_scale * ph[k] * (gHk - doth);
     }
     for (int k = 0; k < a.nd; ++k) gud[k] = 0.f;
-    if (has0) gud[i0] = g.gd0 * softplus_grad(l0);
-    if (has1) gud[i1] = g.gd1 * softplus_grad(l1);
+    if (has0) gud[i0] += g.gd0 * softplus_grad(l0);
+    if (has1) gud[i1] += g.gd1 * softplus_grad(l1);        // circular, one bin: both knots share logit 0
   }
 }
 
@@ -248,7 +249,8 @@ extern "C" int vcnf_rqs_elementwise_bwd_f32(const float* x, const float* uw, con
   if (!cfg) return VCNF_ERR_NULL;
   const int K = cfg->num_bins;
   if (K < 1 || K > kBwdMaxK) return VCNF_ERR_SHAPE;
-  if (cfg->tails != VCNF_TAILS_NONE && cfg->tails != VCNF_TAILS_LINEAR) return VCNF_ERR_UNSUPPORTED;
+  if (cfg->tails != VCNF_TAILS_NONE && cfg->tails != VCNF_TAILS_LINEAR && cfg->tails != VCNF_TAILS_CIRCULAR)
+    return VCNF_ERR_UNSUPPORTED;
   if (cfg->tails == VCNF_TAILS_LINEAR && K < 2) return VCNF_ERR_SHAPE;
   if ((double)cfg->min_bin_width * K > 1.0 || (double)cfg->min_bin_height * K > 1.0) return VCNF_ERR_VALUE;
   if (n < 0 || ld_w < 0 || ld_h < 0 || ld_d < 0) return VCNF_ERR_SHAPE;
@@ -257,7 +259,7 @@ extern "C" int vcnf_rqs_elementwise_bwd_f32(const float* x, const float* uw, con
   BwdArgs a;
   a.x = x; a.uw = uw; a.uh = uh; a.ud = ud; a.ld_w = ld_w; a.ld_h = ld_h; a.ld_d = ld_d;
   a.gy = g_y; a.glad = g_logabsdet; a.gx = g_x; a.guw = g_uw; a.guh = g_uh; a.gud = g_ud; a.n = n;
-  a.nd = cfg->tails == VCNF_TAILS_LINEAR ? K - 1 : K + 1;
+  a.nd = cfg->tails == VCNF_TAILS_LINEAR ? K - 1 : cfg->tails == VCNF_TAILS_CIRCULAR ? K : K + 1;
   RqsConst& c = a.c;
   c.K = K; c.tails = cfg->tails;
   c.lo_x = cfg->left; c.hi_x = cfg->right; c.span_x = (float)((double)cfg->right - (double)cfg->left);

@@ -383,7 +383,8 @@ static int fill_const(const vcnf_rqs_cfg* cfg, RqsConst& c, int& n_deriv) {
   if (!cfg) return VCNF_ERR_NULL;
   const int K = cfg->num_bins;
   if (K < 1 || K > 1024) return VCNF_ERR_SHAPE;
-  if (cfg->tails != VCNF_TAILS_NONE && cfg->tails != VCNF_TAILS_LINEAR) return VCNF_ERR_UNSUPPORTED;
+  if (cfg->tails != VCNF_TAILS_NONE && cfg->tails != VCNF_TAILS_LINEAR && cfg->tails != VCNF_TAILS_CIRCULAR)
+    return VCNF_ERR_UNSUPPORTED;
   if (cfg->tails == VCNF_TAILS_LINEAR && K < 2) return VCNF_ERR_SHAPE;
   // splines.py:104-107
   if ((double)cfg->min_bin_width * K > 1.0 || (double)cfg->min_bin_height * K > 1.0) return VCNF_ERR_VALUE;
@@ -402,7 +403,7 @@ static int fill_const(const vcnf_rqs_cfg* cfg, RqsConst& c, int& n_deriv) {
   c.free_h = (float)(1.0 - (double)cfg->min_bin_height * K);
   c.wh_scale = cfg->wh_scale;
   c.edge_logit = (float)log(exp(1.0 - (double)cfg->min_derivative) - 1.0);
-  n_deriv = cfg->tails == VCNF_TAILS_LINEAR ? K - 1 : K + 1;
+  n_deriv = cfg->tails == VCNF_TAILS_LINEAR ? K - 1 : cfg->tails == VCNF_TAILS_CIRCULAR ? K : K + 1;
   return VCNF_OK;
 }
 

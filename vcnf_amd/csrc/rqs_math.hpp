@@ -22,7 +22,8 @@ namespace vcnf {
 
 struct RqsConst {
   int K;
-  int tails;              // 0 none (K+1 derivative logits), 1 linear (K-1, identity outside)
+  int tails;              // 0 none (K+1 derivative logits), 1 linear (K-1, identity outside),
+                          // 2 circular (K: the last knot shares the first knot's logit, identity outside)
   float lo_x, hi_x, span_x;
   float lo_y, hi_y, span_y;
   float min_w, min_h, min_d;
@@ -155,7 +156,7 @@ __device__ __forceinline__ void rqs_select(float x, const P& p, const RqsConst& 
 template <int KT, bool INV, class P>
 __device__ __forceinline__ void rqs_point(float x, const P& p, const RqsConst& c,
                                           float& y, float& lad, bool& bad) {
-  if (c.tails == 1 && !((x >= c.lo_x) && (x <= c.hi_x))) {
+  if (c.tails != 0 && !((x >= c.lo_x) && (x <= c.hi_x))) {
     y = x;
     lad = 0.f;
     return;
@@ -176,6 +177,7 @@ struct PackedLogits {
   __device__ __forceinline__ float h(int k) const { return q[K + k]; }
   __device__ __forceinline__ float d(int k) const {
     if (tails == 1) return (k == 0 || k == K) ? edge : q[2 * K + k - 1];   // :37-40
+    if (tails == 2) return q[2 * K + (k == K ? 0 : k)];                      // :45-46
     return q[2 * K + k];
   }
 };
@@ -190,6 +192,7 @@ struct SplitLogits {
   __device__ __forceinline__ float h(int k) const { return ph[k]; }
   __device__ __forceinline__ float d(int k) const {
     if (tails == 1) return (k == 0 || k == K) ? edge : pd[k - 1];
+    if (tails == 2) return pd[k == K ? 0 : k];
     return pd[k];
   }
 };
@@ -232,7 +235,7 @@ __device__ __forceinline__ void rqs_build_table(const P& p, const RqsConst& c, f
 template <bool INV, int KT = 0>
 __device__ __forceinline__ void rqs_point_table(float x, const float* tab, const RqsConst& c,
                                                 float& y, float& lad, bool& bad) {
-  if (c.tails == 1 && !((x >= c.lo_x) && (x <= c.hi_x))) {
+  if (c.tails != 0 && !((x >= c.lo_x) && (x <= c.hi_x))) {
     y = x;
     lad = 0.f;
     return;

@@ -98,9 +98,7 @@ class PiecewiseRationalQuadraticCoupling(Flow):
             raise ValueError('Mask can\'t be empty.')
         if isinstance(tails, (list, tuple)) or torch.is_tensor(tail_bound):
             raise NotImplementedError("per-feature tails / tensor tail bounds are not built (SURVEY 8f row 4)")
-        if tails == 'circular':
-            raise NotImplementedError("circular tails are not built (SURVEY 8f row 4)")
-        if tails not in (None, 'linear'):
+        if tails not in (None, 'linear', 'circular'):
             raise RuntimeError('{} tails are not implemented.'.format(tails))
         if img_shape:
             raise NotImplementedError("image-shaped RQS coupling is a next row (SURVEY 8f row 3)")
@@ -145,6 +143,8 @@ class PiecewiseRationalQuadraticCoupling(Flow):
     def _transform_dim_multiplier(self):
         if self.tails == 'linear':
             return self.num_bins * 3 - 1
+        if self.tails == 'circular':
+            return self.num_bins * 3
         return self.num_bins * 3 + 1
 
     # ------------------------------------------------------------ helpers

@@ -1,7 +1,7 @@
 """Functional spline API of the reference (normflow/utils/splines.py) on HIP.
 
 Same names, argument meaning and error behaviour; tensors must live on the GPU.
-Not built: circular tails, per-feature tail lists, tensor
+Not built: per-feature tail lists, tensor
 tail bounds - these raise like an unknown ``tails`` value does in the reference.
 """
 import torch
@@ -47,15 +47,16 @@ def unconstrained_rational_quadratic_spline(inputs, unnormalized_widths, unnorma
                                             min_bin_width=DEFAULT_MIN_BIN_WIDTH,
                                             min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
                                             min_derivative=DEFAULT_MIN_DERIVATIVE):
-    """splines.py:20-85 with linear tails: identity and zero log-det outside
-    [-tail_bound, tail_bound], K-1 derivative logits per element."""
-    if tails != 'linear':
+    """splines.py:20-85: identity and zero log-det outside [-tail_bound, tail_bound]; 'linear'
+    tails take K-1 derivative logits per element (boundary derivatives fixed at 1), 'circular'
+    tails K (the last knot shares the first knot's derivative, :44-49)."""
+    if tails not in ('linear', 'circular'):
         raise RuntimeError('{} tails are not implemented.'.format(tails))
     if torch.is_tensor(tail_bound):
         raise NotImplementedError("tensor tail bounds are not built (SURVEY 8f row 4)")
     num_bins = unnormalized_widths.shape[-1]
     _check_bins(num_bins, min_bin_width, min_bin_height)
-    cfg = _lib.make_cfg(num_bins, 'linear', tail_bound=tail_bound, min_bin_width=min_bin_width,
+    cfg = _lib.make_cfg(num_bins, tails, tail_bound=tail_bound, min_bin_width=min_bin_width,
                         min_bin_height=min_bin_height, min_derivative=min_derivative)
     return _lib.rqs_elementwise(inputs, unnormalized_widths, unnormalized_heights,
                                 unnormalized_derivatives, cfg, inverse)
