@@ -77,6 +77,20 @@ int vcnf_rqs_elementwise_f32(const float* x, const float* uw, const float* uh, c
                              float* y, float* logabsdet, int64_t n,
                              const vcnf_rqs_cfg* cfg, int inverse, int32_t* bad_disc, void* stream);
 
+/* Same spline with general addressing of the logit rows (image-shaped couplings,
+ * coupling.py:148-151, and rows shared by the whole batch, coupling.py:211-240):
+ *   r = period > 0 ? i % period : i;  outer = r / inner;  s = r % inner;
+ *   logit k of element i = u?[outer * row_? + s + k * k_stride].
+ * Conditioner output [B, C*P, H, W] of a 4-D coupling: inner = H*W, k_stride = H*W,
+ * row_* = P*H*W, uh = uw + K*H*W, ud = uw + 2*K*H*W.  Per-pixel logits [C,H,W,K] shared by
+ * the batch: inner = 1, k_stride = 1, row_* = K (K-1 | K | K+1 for ud), period = C*H*W. */
+int vcnf_rqs_elementwise_strided_f32(const float* x, const float* uw, const float* uh, const float* ud,
+                                     int64_t row_w, int64_t row_h, int64_t row_d, int64_t inner,
+                                     int64_t k_stride, int64_t period,
+                                     float* y, float* logabsdet, int64_t n,
+                                     const vcnf_rqs_cfg* cfg, int inverse, int32_t* bad_discriminant,
+                                     void* stream);
+
 /* Vector-Jacobian product of vcnf_rqs_elementwise_f32 (training path; the reference
  * obtains it from autograd over utils/splines.py:88-193).  Inputs as the forward call
  * plus the upstream gradients g_y[n], g_logabsdet[n]; outputs g_x[n] and dense

@@ -74,9 +74,13 @@ class RQSCoupling:
         self.mins = (min_bin_width, min_bin_height, min_derivative)
 
     def _spline(self, x, params, inverse):
-        """coupling.py:147-159 + :309-343 for 2-D inputs."""
-        b, d = x.shape
-        p = params.reshape(b, d, -1)                            # :155
+        """coupling.py:147-159 + :309-343; 4-D inputs: Bx(C*P)xHxW -> BxCxHxWxP (:148-151)."""
+        if x.dim() == 4:
+            b, c, h, w = x.shape
+            p = params.reshape(b, c, -1, h, w).permute(0, 1, 3, 4, 2)   # :151
+        else:
+            b, d = x.shape
+            p = params.reshape(b, d, -1)                        # :155
         uw = p[..., :self.k]
         uh = p[..., self.k:2 * self.k]
         ud = p[..., 2 * self.k:]

@@ -4,6 +4,7 @@ layers whose outputs parameterise the bijector.
 
 * ``residual_net`` <- ``normflow/nets/resnet.py`` ResidualNet :60-106,
   ResidualBlock :8-57 (no batch norm, dropout p=0 -> identity)
+* ``conv_residual_net`` <- ``normflow/nets/resnet.py`` ConvResidualNet :163-212, ConvResidualBlock :109-160
 * ``mlp``          <- ``normflow/nets/mlp.py`` MLP :7-58 (Linear + LeakyReLU)
 """
 import torch
@@ -31,6 +32,26 @@ def residual_net(sd, prefix, x, context=None, activation=F.relu):
         h = h + t                                           # :57
         i += 1
     return _lin(sd, prefix + "final_layer", h)              # :105
+
+
+def conv_residual_net(sd, prefix, x, context=None, activation=F.relu):
+    """resnet.py:199-212 (ConvResidualNet) with ConvResidualBlock :139-160: 1x1 conv on
+    cat(x, context), blocks of two 3x3 convs with an optional GLU gate from a 1x1 conv of the
+    context image, 1x1 conv out (no batch norm, dropout p=0)."""
+    conv = lambda key, t, pad: F.conv2d(t, sd[key + ".weight"], sd[key + ".bias"], padding=pad)
+    h = conv(prefix + "initial_layer", x if context is None else torch.cat((x, context), dim=1), 0)
+    i = 0
+    while (prefix + "blocks.%d.conv_layers.0.weight" % i) in sd:
+        bp = prefix + "blocks.%d." % i
+        t = activation(h)                                   # :143
+        t = conv(bp + "conv_layers.0", t, 1)                # :144
+        t = activation(t)                                   # :147
+        t = conv(bp + "conv_layers.1", t, 1)                # :149
+        if context is not None:                             # :150-158
+            t = F.glu(torch.cat((t, conv(bp + "context_layer", context, 0)), dim=1), dim=1)
+        h = h + t                                           # :159
+        i += 1
+    return conv(prefix + "final_layer", h, 0)               # :211
 
 
 def mlp(sd, prefix, x, leaky=0.0):

@@ -596,6 +596,38 @@ def g16_circular():
     save("g16_circular", **out)
 
 
+# ---------------------------------------------------------------- G17
+def g17_image_rqs():
+    """Image-shaped RQS coupling [B, C, H, W] (coupling.py:148-151): channel mask, convolutional
+    conditioner (ConvResidualNet, with and without a context image), per-pixel unconditional
+    spline on the identity channels (img_shape), linear tails."""
+    from normflow.nets.resnet import ConvResidualNet
+    out = {}
+    c, h, w, k, tb, hid = 6, 4, 4, 8, 3.0, 16
+    r = rng(1700)
+    x = torch.from_numpy((1.2 * r.standard_normal((32, c, h, w))).astype(np.float32))
+    ctx = torch.from_numpy(r.standard_normal((32, 2, h, w)).astype(np.float32))
+    out["x"], out["ctx"] = npy(x), npy(ctx)
+    for tag, cc in (("noctx", None), ("ctx", 2)):
+        def build():
+            net = lambda i, o: ConvResidualNet(in_channels=i, out_channels=o, hidden_channels=hid,
+                                               context_channels=cc, num_blocks=1,
+                                               activation=torch.nn.functional.relu,
+                                               dropout_probability=0.0, use_batch_norm=False)
+            return PiecewiseRationalQuadraticCoupling(
+                mask=ref_masks.create_alternating_binary_mask(c, even=True), transform_net_create_fn=net,
+                num_bins=k, tails="linear", tail_bound=tb, apply_unconditional_transform=True, img_shape=[h, w])
+        if cc is None:
+            call = lambda m, a: m.forward(a) + m.inverse(a)
+            inputs = [x]
+        else:
+            call = lambda m, a, b: m.forward(a, b) + m.inverse(a, b)
+            inputs = [x, ctx]
+        ents, ints, o32, o64, _ = run_module_case(build, 1701, inputs, call, final_gain=2.0)
+        pack(out, tag, ents, ints, ["nsf_fwd_z", "nsf_fwd_ld", "nsf_inv_z", "nsf_inv_ld"], o32, o64)
+    save("g17_image_rqs", **out)
+
+
 if __name__ == "__main__":
     g1_rqs()
     g2_tails()
@@ -613,3 +645,4 @@ if __name__ == "__main__":
     g14_lu_linear_permute()
     g15_checkerboard()
     g16_circular()
+    g17_image_rqs()

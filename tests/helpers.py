@@ -47,6 +47,15 @@ def oracle_rqs_coupling(sd, prefix, num_bins, tail_bound, hidden, tails="linear"
                           cond, num_bins, tails, tail_bound, hidden_features=hidden, uncond=uncond)
 
 
+def oracle_image_rqs_coupling(sd, num_bins=8, tail_bound=3.0, hidden=16):
+    """Oracle image-shaped coupling of fixture G17 (keys at top level, ConvResidualNet conditioner)."""
+    uncond = OL.RQSCDF(sd["unconditional_transform.unnormalized_widths"], sd["unconditional_transform.unnormalized_heights"],
+                       sd["unconditional_transform.unnormalized_derivatives"], "linear", tail_bound)
+    cond = lambda x, ctx: ON.conv_residual_net(sd, "transform_net.", x, ctx, F.relu)
+    return OL.RQSCoupling(sd["identity_features"], sd["transform_features"], cond, num_bins, "linear", tail_bound,
+                          hidden_features=hidden, uncond=uncond)
+
+
 def oracle_c3_stack(sd, layers=12, num_bins=8, tail_bound=3.0, hidden=128):
     flows = [oracle_rqs_coupling(sd, "flows.%d.prqct." % i, num_bins, tail_bound, hidden)
              for i in range(layers)]

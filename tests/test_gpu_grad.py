@@ -356,3 +356,18 @@ def test_nsf_stack_with_lu_linear_permute_trains(hip):
         first = float(loss.detach()) if first is None else first
         last = float(loss.detach())
     assert np.isfinite(last) and last < first - 0.3, (first, last)
+
+
+def test_image_rqs_coupling_gradients(hip):
+    from helpers import oracle_image_rqs_coupling
+    from test_gpu_parity import _image_coupling
+    fx = fixture("g17_image_rqs")
+    sd, _ = state_for(fx, "ctx", 1701, final_gain=2.0)
+    m = _image_coupling(2)
+    m.load_state_dict(sd)
+    m = m.to("cuda")
+    pick = lambda out: (out[0] ** 2).mean() + out[1].mean()
+    for dirn in ("forward", "inverse"):
+        ofn = "nsf_forward" if dirn == "forward" else "nsf_inverse"
+        _grad_compare(getattr(m, dirn), lambda s, x, c: getattr(oracle_image_rqs_coupling(s), ofn)(x, c), sd,
+                      [T(fx["x"]), T(fx["ctx"])], "image rqs " + dirn, loss_of=pick)

@@ -289,3 +289,18 @@ def test_g16_circular_coupling_layer():
             z, ld = fn(x, ctx)
             assert_close(z, fx["layer/%s_z%s" % (dirn, suf)], what=dirn + " z", **tol)
             assert_close(ld, fx["layer/%s_ld%s" % (dirn, suf)], what=dirn + " ld", **tol)
+
+
+@pytest.mark.parametrize("tag", ["noctx", "ctx"])
+def test_g17_image_rqs_coupling(tag):
+    from helpers import oracle_image_rqs_coupling
+    fx = fixture("g17_image_rqs")
+    for dt, suf, tol in ((torch.float32, "32", dict(rtol=2e-5, atol=2e-5)), (torch.float64, "64", F64)):
+        sd, _ = state_for(fx, tag, 1701, dt, final_gain=2.0)
+        lay = oracle_image_rqs_coupling(sd)
+        x = T(fx["x"], dt)
+        ctx = T(fx["ctx"], dt) if tag == "ctx" else None
+        for dirn, fn in (("nsf_fwd", lay.nsf_forward), ("nsf_inv", lay.nsf_inverse)):
+            z, ld = fn(x, ctx)
+            assert_close(z, fx["%s/%s_z%s" % (tag, dirn, suf)], what=dirn + " z", **tol)
+            assert_close(ld, fx["%s/%s_ld%s" % (tag, dirn, suf)], what=dirn + " ld", **tol)

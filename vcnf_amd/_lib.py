@@ -36,6 +36,8 @@ PROTOTYPES = {
     "vcnf_status_string": ([_INT], ctypes.c_char_p),
     "vcnf_rqs_elementwise_f32": ([_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _I64,
                                   ctypes.POINTER(RqsCfg), _INT, _P, _P], _INT),
+    "vcnf_rqs_elementwise_strided_f32": ([_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _I64,
+                                          ctypes.POINTER(RqsCfg), _INT, _P, _P], _INT),
     "vcnf_rqs_elementwise_bwd_f32": ([_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _I64,
                                       ctypes.POINTER(RqsCfg), _INT, _P], _INT),
     "vcnf_rqs_coupling_f32": ([_P, _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _I64,
@@ -207,6 +209,52 @@ def rqs_elementwise(x, uw, uh, ud, cfg, inverse, allow_grad=False):
                                             _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
     _check(st, "vcnf_rqs_elementwise_f32")
     return y.view(shape), lad.view(shape)
+
+
+def rqs_elementwise_image(x, params, cfg, inverse):
+    """x [B, C, *inner] with the conditioner output params [B, C*P, *inner] read in place
+    (the reference reshapes/permutes it to [B, C, *inner, P]; coupling.py:148-151)."""
+    dev = require_device(x, params)
+    k, nd = cfg.num_bins, n_derivatives(cfg)
+    p = 2 * k + nd
+    b, c = x.shape[0], x.shape[1]
+    inner = int(x[0, 0].numel())
+    if tuple(params.shape) != (b, c * p) + tuple(x.shape[2:]):
+        raise VcnfError("conditioner output %s does not match inputs %s with %d logits per element" % (
+            tuple(params.shape), tuple(x.shape), p))
+    x = x.contiguous()
+    params = params.contiguous()
+    y, lad = torch.empty_like(x), torch.empty_like(x)
+    base = params.data_ptr()
+    with torch.cuda.device(dev):
+        st = lib().vcnf_rqs_elementwise_strided_f32(
+            _ptr(x), base, base + 4 * k * inner, base + 8 * k * inner, p * inner, p * inner, p * inner,
+            inner, inner, 0, _ptr(y), _ptr(lad), x.numel(), ctypes.byref(cfg), int(bool(inverse)),
+            _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
+    _check(st, "vcnf_rqs_elementwise_strided_f32")
+    return y, lad
+
+
+def rqs_elementwise_shared(x, uw, uh, ud, cfg, inverse):
+    """x [B, *shape] with one logit row per position of ``shape`` shared by the whole batch:
+    uw, uh [*shape, K], ud [*shape, nd] (PiecewiseRationalQuadraticCDF, coupling.py:211-240)."""
+    dev = require_device(x, uw, uh, ud)
+    k, nd = cfg.num_bins, n_derivatives(cfg)
+    shape = tuple(x.shape[1:])
+    if tuple(uw.shape) != shape + (k,) or tuple(uh.shape) != shape + (k,) or tuple(ud.shape) != shape + (nd,):
+        raise VcnfError("shared spline logits %s %s %s do not match positions %s with K=%d" % (
+            tuple(uw.shape), tuple(uh.shape), tuple(ud.shape), shape, k))
+    x = x.contiguous()
+    uw, uh, ud = uw.contiguous(), uh.contiguous(), ud.contiguous()
+    y, lad = torch.empty_like(x), torch.empty_like(x)
+    period = int(x[0].numel())
+    with torch.cuda.device(dev):
+        st = lib().vcnf_rqs_elementwise_strided_f32(
+            _ptr(x), _ptr(uw), _ptr(uh), _ptr(ud), k, k, nd, 1, 1, period, _ptr(y), _ptr(lad), x.numel(),
+            ctypes.byref(cfg), int(bool(inverse)),
+            _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
+    _check(st, "vcnf_rqs_elementwise_strided_f32")
+    return y, lad
 
 
 def rqs_elementwise_bwd(x, uw, uh, ud, gy, glad, cfg, inverse):

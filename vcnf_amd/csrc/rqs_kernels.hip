@@ -320,6 +320,46 @@ __global__ __launch_bounds__(kBlock) void rqs_elementwise_kernel(const ElemArgs 
   if (INV && a.bad && bad) atomicAdd(a.bad, 1);
 }
 
+// General addressing of the per-element logit rows (images, batch-shared rows):
+//   r = period > 0 ? i % period : i;  outer = r / inner;  s = r % inner;
+//   logit k of element i at  base + outer * row + s + k * ks   (row per tensor: row_w, row_h, row_d).
+struct ElemStridedArgs {
+  const float *x, *uw, *uh, *ud;
+  long long row_w, row_h, row_d, inner, ks, period;
+  float *y, *lad;
+  int32_t* bad;
+  long long n;
+  RqsConst c;
+};
+
+template <int KT, bool INV>
+__global__ __launch_bounds__(kBlock) void rqs_elementwise_strided_kernel(const ElemStridedArgs a) {
+  const int K = KT > 0 ? KT : a.c.K;
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (long long)gridDim.x * kBlock) {
+    const long long r = a.period > 0 ? i % a.period : i;
+    const long long outer = r / a.inner, s = r - outer * a.inner;
+    StridedLogits p{a.uw + outer * a.row_w + s, a.uh + outer * a.row_h + s, a.ud + outer * a.row_d + s, a.ks,
+                    K, a.c.wh_scale, a.c.edge_logit, a.c.tails};
+    float yv, lad;
+    rqs_point<KT, INV>(a.x[i], p, a.c, yv, lad, bad);
+    a.y[i] = yv;
+    a.lad[i] = lad;
+  }
+  if (INV && a.bad && bad) atomicAdd(a.bad, 1);
+}
+
+template <bool INV>
+static void launch_elem_strided(const ElemStridedArgs& a, int K, dim3 grid, hipStream_t st) {
+  switch (K) {
+    case 4: hipLaunchKernelGGL((rqs_elementwise_strided_kernel<4, INV>), grid, dim3(kBlock), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((rqs_elementwise_strided_kernel<8, INV>), grid, dim3(kBlock), 0, st, a); break;
+    case 10: hipLaunchKernelGGL((rqs_elementwise_strided_kernel<10, INV>), grid, dim3(kBlock), 0, st, a); break;
+    case 16: hipLaunchKernelGGL((rqs_elementwise_strided_kernel<16, INV>), grid, dim3(kBlock), 0, st, a); break;
+    default: hipLaunchKernelGGL((rqs_elementwise_strided_kernel<0, INV>), grid, dim3(kBlock), 0, st, a); break;
+  }
+}
+
 // ------------------------------------------------------------------ conditioner input
 struct CondInArgs {
   const float* x;
@@ -571,6 +611,29 @@ extern "C" int vcnf_rqs_elementwise_f32(const float* x, const float* uw, const f
   hipStream_t st = (hipStream_t)stream;
   if (inverse) launch_elem<true>(a, a.c.K, grid, st);
   else launch_elem<false>(a, a.c.K, grid, st);
+  return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
+}
+
+extern "C" int vcnf_rqs_elementwise_strided_f32(const float* x, const float* uw, const float* uh, const float* ud,
+                                                int64_t row_w, int64_t row_h, int64_t row_d, int64_t inner,
+                                                int64_t k_stride, int64_t period,
+                                                float* y, float* logabsdet, int64_t n,
+                                                const vcnf_rqs_cfg* cfg, int inverse, int32_t* bad_disc, void* stream) {
+  ElemStridedArgs a;
+  int nd = 0;
+  const int rc = fill_const(cfg, a.c, nd);
+  if (rc != VCNF_OK) return rc;
+  if (n < 0 || row_w < 0 || row_h < 0 || row_d < 0 || inner < 1 || k_stride < 1 || period < 0) return VCNF_ERR_SHAPE;
+  if (n == 0) return VCNF_OK;
+  if (!x || !uw || !uh || !y || !logabsdet || (nd > 0 && !ud)) return VCNF_ERR_NULL;
+  a.x = x; a.uw = uw; a.uh = uh; a.ud = ud; a.row_w = row_w; a.row_h = row_h; a.row_d = row_d;
+  a.inner = inner; a.ks = k_stride; a.period = period;
+  a.y = y; a.lad = logabsdet; a.bad = bad_disc; a.n = n;
+  const long long blocks = (n + kBlock - 1) / kBlock;
+  dim3 grid((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16));
+  hipStream_t st = (hipStream_t)stream;
+  if (inverse) launch_elem_strided<true>(a, a.c.K, grid, st);
+  else launch_elem_strided<false>(a, a.c.K, grid, st);
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }
 

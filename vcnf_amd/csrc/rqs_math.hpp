@@ -197,6 +197,23 @@ struct SplitLogits {
   }
 };
 
+// Logit rows with an element stride between consecutive k (image layout: the conditioner emits
+// [B, C*P, H, W], so the P logits of one pixel are H*W floats apart; coupling.py:148-151).
+struct StridedLogits {
+  const float *pw, *ph, *pd;
+  long long ks;
+  int K;
+  float scale, edge;
+  int tails;
+  __device__ __forceinline__ float w(int k) const { return pw[k * ks]; }
+  __device__ __forceinline__ float h(int k) const { return ph[k * ks]; }
+  __device__ __forceinline__ float d(int k) const {
+    if (tails == 1) return (k == 0 || k == K) ? edge : pd[(k - 1) * ks];
+    if (tails == 2) return pd[(k == K ? 0 : k) * ks];
+    return pd[k * ks];
+  }
+};
+
 // Per-feature knot table for batch-shared logits (PiecewiseRationalQuadraticCDF,
 // coupling.py:165-246): xk[K+1] | yk[K+1] | dk[K+1], built once per workgroup with
 // the same arithmetic as rqs_select, so table and direct evaluation agree bitwise.

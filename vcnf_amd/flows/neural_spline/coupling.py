@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from ..base import Flow
-from ... import _lib, fused
+from ... import _lib, fused, autograd
 from ...utils import splines
 
 
@@ -61,16 +61,21 @@ class PiecewiseRationalQuadraticCDF(Flow):
     def logits(self):
         return (self.unnormalized_widths, self.unnormalized_heights, self.unnormalized_derivatives)
 
+    def _cfg(self):
+        return _lib.make_cfg(self.num_bins, self.tails, tail_bound=self.tail_bound,
+                             min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                             min_derivative=self.min_derivative)
+
     def _spline(self, inputs, inverse):
-        n = inputs.shape[0]
-        uw, uh, ud = (p[None, ...].expand(n, *p.shape) for p in self.logits())
-        kw = dict(inverse=inverse, min_bin_width=self.min_bin_width,
-                  min_bin_height=self.min_bin_height, min_derivative=self.min_derivative)
-        if self.tails is None:
-            out, lad = splines.rational_quadratic_spline(inputs, uw, uh, ud, **kw)
+        if tuple(inputs.shape[1:]) != tuple(self.unnormalized_widths.shape[:-1]):
+            raise ValueError('Expected inputs of shape [B, {}], got {}.'.format(
+                tuple(self.unnormalized_widths.shape[:-1]), tuple(inputs.shape)))
+        splines._check_bins(self.num_bins, self.min_bin_width, self.min_bin_height)
+        if autograd.needs_grad(inputs, *self.logits()):
+            out, lad = autograd.rqs_spline(inputs, *self.logits(), self._cfg(), inverse=inverse)
         else:
-            out, lad = splines.unconstrained_rational_quadratic_spline(
-                inputs, uw, uh, ud, tails=self.tails, tail_bound=self.tail_bound, **kw)
+            # one logit row per position, shared by the batch: read in place (no [B, ...] expansion)
+            out, lad = _lib.rqs_elementwise_shared(inputs, *self.logits(), self._cfg(), inverse)
         return out, torch.sum(lad, dim=list(range(1, lad.dim())))
 
     def forward(self, inputs, context=None):
@@ -100,9 +105,8 @@ class PiecewiseRationalQuadraticCoupling(Flow):
             raise NotImplementedError("per-feature tails / tensor tail bounds are not built (SURVEY 8f row 4)")
         if tails not in (None, 'linear', 'circular'):
             raise RuntimeError('{} tails are not implemented.'.format(tails))
-        if img_shape:
-            raise NotImplementedError("image-shaped RQS coupling is a next row (SURVEY 8f row 3)")
         super().__init__()
+        self.img_shape = list(img_shape) if img_shape else None
         self.num_bins = num_bins
         self.min_bin_width = min_bin_width
         self.min_bin_height = min_bin_height
@@ -119,7 +123,7 @@ class PiecewiseRationalQuadraticCoupling(Flow):
             self.num_identity_features, self.num_transform_features * self._transform_dim_multiplier())
         if apply_unconditional_transform:
             self.unconditional_transform = PiecewiseRationalQuadraticCDF(
-                shape=[self.num_identity_features], num_bins=num_bins, tails=tails,
+                shape=[self.num_identity_features] + (self.img_shape or []), num_bins=num_bins, tails=tails,
                 tail_bound=tail_bound, min_bin_width=min_bin_width,
                 min_bin_height=min_bin_height, min_derivative=min_derivative)
         else:
@@ -178,8 +182,6 @@ class PiecewiseRationalQuadraticCoupling(Flow):
             raise ValueError('Inputs must be a 2D or a 4D tensor.')
         if inputs.shape[1] != self.features:
             raise ValueError('Expected features = {}, got {}.'.format(self.features, inputs.shape[1]))
-        if inputs.dim() == 4:
-            raise NotImplementedError("image-shaped RQS coupling is a next row (SURVEY 8f row 3)")
 
     def _params(self, inputs, context, sampling):
         """Conditioner call.  Sampling direction: the identity half first goes
@@ -226,8 +228,43 @@ class PiecewiseRationalQuadraticCoupling(Flow):
         out[:, self.transform_features] = yt
         return out, lad
 
+    def _run_image(self, inputs, context, sampling):
+        """4-D inputs [B, C, H, W], mask over channels (coupling.py:70-125 with :148-151): channel
+        gather / scatter and the convolutional conditioner are PyTorch-ROCm ops; the splines read
+        the conditioner output [B, C_t*P, H, W] in place through the strided elementwise kernel
+        (the reference reshapes and permutes it to [B, C_t, H, W, P] first)."""
+        k = self.num_bins
+        uncond = self.unconditional_transform
+        grad = self._needs_grad(inputs, context)
+        xi = inputs[:, self.identity_features]
+        xt = inputs[:, self.transform_features]
+        lad = 0.0
+        if sampling and uncond is not None:
+            xi, lad = uncond.inverse(xi)
+        params = self.transform_net(xi, context) if context is not None else self.transform_net(xi)
+        if grad:
+            b, c, h, w = xt.shape
+            p = params.reshape(b, c, -1, h, w).permute(0, 1, 3, 4, 2)
+            yt, le = autograd.rqs_spline(xt.contiguous(), p[..., :k], p[..., k:2 * k], p[..., 2 * k:],
+                                         self._cfg(True), inverse=sampling)
+        else:
+            yt, le = _lib.rqs_elementwise_image(xt, params, self._cfg(True), sampling)
+        lad = lad + le.sum(dim=(1, 2, 3))
+        if (not sampling) and uncond is not None:
+            xi, l2 = uncond.forward(xi)
+            lad = lad + l2
+        out = torch.empty_like(inputs)
+        out[:, self.identity_features] = xi
+        out[:, self.transform_features] = yt
+        return out, lad
+
     def _run(self, inputs, context, sampling, log_q=None, sign=1.0):
         self._check(inputs)
+        if inputs.dim() == 4:
+            out, lad = self._run_image(inputs, context, sampling)
+            if log_q is not None:
+                return out, log_q.add_(lad, alpha=sign)
+            return out, (lad if sign == 1.0 else sign * lad)
         if self._needs_grad(inputs, context):
             out, lad = self._run_differentiable(inputs, context, sampling)
             if log_q is not None:

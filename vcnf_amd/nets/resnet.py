@@ -75,3 +75,60 @@ class ResidualNet(nn.Module):
         for block in self.blocks:
             h = block(h, context=context)
         return self.final_layer(h)
+
+
+class ConvResidualBlock(nn.Module):
+    """Image form of ResidualBlock: two 3x3 convolutions, optional GLU gate from a 1x1
+    projection of the context image (resnet.py:109-160)."""
+
+    def __init__(self, channels, context_channels=None, activation=F.relu,
+                 dropout_probability=0., use_batch_norm=False, zero_initialization=True):
+        super().__init__()
+        self.activation = activation
+        if context_channels is not None:
+            self.context_layer = nn.Conv2d(context_channels, channels, kernel_size=1, padding=0)
+        self.use_batch_norm = use_batch_norm
+        if use_batch_norm:
+            self.batch_norm_layers = nn.ModuleList([nn.BatchNorm2d(channels, eps=1e-3) for _ in range(2)])
+        self.conv_layers = nn.ModuleList([nn.Conv2d(channels, channels, kernel_size=3, padding=1) for _ in range(2)])
+        self.dropout = nn.Dropout(p=dropout_probability)
+        if zero_initialization:
+            for p in (self.conv_layers[1].weight, self.conv_layers[1].bias):
+                nn.init.uniform_(p, -1e-3, 1e-3)
+
+    def forward(self, inputs, context=None):
+        h = inputs
+        for i in range(2):
+            if self.use_batch_norm:
+                h = self.batch_norm_layers[i](h)
+            h = self.activation(h)
+            if i == 1:
+                h = self.dropout(h)
+            h = self.conv_layers[i](h)
+        if context is not None:
+            h = F.glu(torch.cat((h, self.context_layer(context)), dim=1), dim=1)
+        return inputs + h
+
+
+class ConvResidualNet(nn.Module):
+    """1x1 conv -> num_blocks x ConvResidualBlock -> 1x1 conv: conditioner of the image-shaped
+    RQS coupling (resnet.py:163-212).  Convolutions run on PyTorch-ROCm (MIOpen)."""
+
+    def __init__(self, in_channels, out_channels, hidden_channels, context_channels=None,
+                 num_blocks=2, activation=F.relu, dropout_probability=0., use_batch_norm=False):
+        super().__init__()
+        self.context_channels = context_channels
+        self.hidden_channels = hidden_channels      # read by the coupling for the 1/sqrt(H) logit scale
+        self.initial_layer = nn.Conv2d(in_channels + (context_channels or 0), hidden_channels, kernel_size=1, padding=0)
+        self.blocks = nn.ModuleList([
+            ConvResidualBlock(hidden_channels, context_channels, activation=activation,
+                              dropout_probability=dropout_probability, use_batch_norm=use_batch_norm)
+            for _ in range(num_blocks)])
+        self.final_layer = nn.Conv2d(hidden_channels, out_channels, kernel_size=1, padding=0)
+
+    def forward(self, inputs, context=None):
+        h = inputs if context is None else torch.cat((inputs, context), dim=1)
+        h = self.initial_layer(h)
+        for block in self.blocks:
+            h = block(h, context)
+        return self.final_layer(h)
