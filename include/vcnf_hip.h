@@ -101,6 +101,26 @@ int vcnf_rqs_elementwise_bwd_f32(const float* x, const float* uw, const float* u
                                  float* g_x, float* g_uw, float* g_uh, float* g_ud, int64_t n,
                                  const vcnf_rqs_cfg* cfg, int inverse, void* stream);
 
+/* VJP of the spline with the logits read from (and their gradient written in) the conditioner's
+ * own output layout: params / g_params [rows, P, inner] with P = 2K + (K-1 | K | K+1), x [rows*inner]
+ * (2-D coupling: inner = 1, rows = B*d_t; image coupling: inner = H*W, rows = B*C_t).  g_logabsdet
+ * is read at i / lad_div (per-sample log-det: lad_div = elements per sample). */
+int vcnf_rqs_packed_bwd_f32(const float* x, const float* params, int64_t inner, int64_t lad_div,
+                            const float* g_y, const float* g_logabsdet,
+                            float* g_x, float* g_params, int64_t n,
+                            const vcnf_rqs_cfg* cfg, int inverse, void* stream);
+
+/* VJP of the batch-shared spline (coupling.py:211-240): x [batch, period], logits sw, sh [period, K],
+ * sd [period, nd].  Writes g_x and `groups` partial gradient rows per position,
+ * partial [groups, period, 2K+nd] (sum over the first axis = gradient of the logits, row layout
+ * w | h | d); groups must equal vcnf_rqs_shared_bwd_groups(batch, period).  K in {4, 8, 10, 16}. */
+int64_t vcnf_rqs_shared_bwd_groups(int64_t batch, int64_t period);
+int vcnf_rqs_shared_bwd_f32(const float* x, const float* sw, const float* sh, const float* sd,
+                            int64_t batch, int64_t period, int64_t lad_div,
+                            const float* g_y, const float* g_logabsdet,
+                            float* g_x, float* partial, int64_t groups,
+                            const vcnf_rqs_cfg* cfg, int inverse, void* stream);
+
 /* One RQS coupling layer on x[B,D] -> y[B,D].
  * Replaces Coupling.forward / .inverse (flows/neural_spline/coupling.py:70-96 /
  * :98-125) minus the conditioner call, PiecewiseCoupling._coupling_transform

@@ -40,6 +40,10 @@ PROTOTYPES = {
                                           ctypes.POINTER(RqsCfg), _INT, _P, _P], _INT),
     "vcnf_rqs_elementwise_bwd_f32": ([_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _I64,
                                       ctypes.POINTER(RqsCfg), _INT, _P], _INT),
+    "vcnf_rqs_packed_bwd_f32": ([_P, _P, _I64, _I64, _P, _P, _P, _P, _I64, ctypes.POINTER(RqsCfg), _INT, _P], _INT),
+    "vcnf_rqs_shared_bwd_groups": ([_I64, _I64], _I64),
+    "vcnf_rqs_shared_bwd_f32": ([_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _I64,
+                                 ctypes.POINTER(RqsCfg), _INT, _P], _INT),
     "vcnf_rqs_coupling_f32": ([_P, _P, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _I64,
                                ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P], _INT),
     "vcnf_rqs_conditioner_input_f32": ([_P, _I64, _I32, _P, _I32, _P, _I32, _P, _P, _P,
@@ -211,10 +215,10 @@ def rqs_elementwise(x, uw, uh, ud, cfg, inverse, allow_grad=False):
     return y.view(shape), lad.view(shape)
 
 
-def rqs_elementwise_image(x, params, cfg, inverse):
+def rqs_elementwise_image(x, params, cfg, inverse, allow_grad=False):
     """x [B, C, *inner] with the conditioner output params [B, C*P, *inner] read in place
     (the reference reshapes/permutes it to [B, C, *inner, P]; coupling.py:148-151)."""
-    dev = require_device(x, params)
+    dev = require_device(x, params, allow_grad=allow_grad)
     k, nd = cfg.num_bins, n_derivatives(cfg)
     p = 2 * k + nd
     b, c = x.shape[0], x.shape[1]
@@ -235,10 +239,10 @@ def rqs_elementwise_image(x, params, cfg, inverse):
     return y, lad
 
 
-def rqs_elementwise_shared(x, uw, uh, ud, cfg, inverse):
+def rqs_elementwise_shared(x, uw, uh, ud, cfg, inverse, allow_grad=False):
     """x [B, *shape] with one logit row per position of ``shape`` shared by the whole batch:
     uw, uh [*shape, K], ud [*shape, nd] (PiecewiseRationalQuadraticCDF, coupling.py:211-240)."""
-    dev = require_device(x, uw, uh, ud)
+    dev = require_device(x, uw, uh, ud, allow_grad=allow_grad)
     k, nd = cfg.num_bins, n_derivatives(cfg)
     shape = tuple(x.shape[1:])
     if tuple(uw.shape) != shape + (k,) or tuple(uh.shape) != shape + (k,) or tuple(ud.shape) != shape + (nd,):
@@ -255,6 +259,44 @@ def rqs_elementwise_shared(x, uw, uh, ud, cfg, inverse):
             _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
     _check(st, "vcnf_rqs_elementwise_strided_f32")
     return y, lad
+
+
+def rqs_packed_bwd(x, params, gy, glad, cfg, inverse):
+    """VJP of rqs_elementwise_image: x, gy [B, C, *inner]; params [B, C*P, *inner]; glad [B]
+    (gradient of the per-sample log-det).  Returns (g_x, g_params) in the layouts of x / params."""
+    dev = require_device(x, params, gy, glad, allow_grad=True)
+    x, params = x.detach().contiguous(), params.detach().contiguous()
+    gy, glad = gy.detach().contiguous(), glad.detach().contiguous()
+    inner = int(x[0, 0].numel())
+    gx, gp = torch.empty_like(x), torch.empty_like(params)
+    with torch.cuda.device(dev):
+        st = lib().vcnf_rqs_packed_bwd_f32(_ptr(x), _ptr(params), inner, int(x[0].numel()), _ptr(gy), _ptr(glad),
+                                           _ptr(gx), _ptr(gp), x.numel(), ctypes.byref(cfg),
+                                           int(bool(inverse)), _stream())
+    _check(st, "vcnf_rqs_packed_bwd_f32")
+    return gx, gp
+
+
+SHARED_BWD_BINS = (4, 8, 10, 16)
+
+
+def rqs_shared_bwd(x, uw, uh, ud, gy, glad, cfg, inverse):
+    """VJP of rqs_elementwise_shared: x, gy [B, *shape]; glad [B]; returns (g_x, g_uw, g_uh, g_ud)."""
+    dev = require_device(x, uw, uh, ud, gy, glad, allow_grad=True)
+    k, nd = cfg.num_bins, n_derivatives(cfg)
+    x, gy, glad = x.detach().contiguous(), gy.detach().contiguous(), glad.detach().contiguous()
+    uw, uh, ud = uw.detach().contiguous(), uh.detach().contiguous(), ud.detach().contiguous()
+    b, period = x.shape[0], int(x[0].numel())
+    groups = int(lib().vcnf_rqs_shared_bwd_groups(b, period))
+    gx = torch.empty_like(x)
+    partial = torch.empty(groups, period, 2 * k + nd, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = lib().vcnf_rqs_shared_bwd_f32(_ptr(x), _ptr(uw), _ptr(uh), _ptr(ud), b, period, period,
+                                           _ptr(gy), _ptr(glad), _ptr(gx), _ptr(partial), groups,
+                                           ctypes.byref(cfg), int(bool(inverse)), _stream())
+    _check(st, "vcnf_rqs_shared_bwd_f32")
+    g = partial.sum(0)
+    return gx, g[:, :k].reshape(uw.shape), g[:, k:2 * k].reshape(uh.shape), g[:, 2 * k:].reshape(ud.shape)
 
 
 def rqs_elementwise_bwd(x, uw, uh, ud, gy, glad, cfg, inverse):

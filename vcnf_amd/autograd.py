@@ -36,6 +36,62 @@ def rqs_spline(x, uw, uh, ud, cfg, inverse=False):
                              ud.expand(x.shape + ud.shape[-1:]), cfg, inverse)
 
 
+class RqsPackedFn(torch.autograd.Function):
+    """Transform half of a coupling: (y, logabsdet[B]) = spline(x; params) with x [B, C, *inner]
+    and the conditioner output params [B, C*P, *inner] used in place, forward and backward: the
+    gradient comes back in the conditioner's own output layout (no slicing, no permute, no
+    per-tensor copies)."""
+
+    @staticmethod
+    def forward(ctx, x, params, cfg, inverse):
+        with torch.no_grad():
+            y, lad = _lib.rqs_elementwise_image(x, params, cfg, inverse, allow_grad=True)
+        ctx.save_for_backward(x, params)
+        ctx.cfg, ctx.inverse = cfg, inverse
+        return y, lad.reshape(lad.shape[0], -1).sum(1)
+
+    @staticmethod
+    def backward(ctx, gy, glad):
+        x, params = ctx.saved_tensors
+        gx, gp = _lib.rqs_packed_bwd(x, params, gy, glad, ctx.cfg, ctx.inverse)
+        return gx, gp, None, None
+
+
+class RqsSharedFn(torch.autograd.Function):
+    """Identity half of a coupling: per-position spline whose logits are shared by the batch.
+    Backward reduces the logit gradient over the batch inside the kernel (per-thread knot
+    adjoints, one Jacobian application per thread) instead of materialising [B, ..., 3K-1]."""
+
+    @staticmethod
+    def forward(ctx, x, uw, uh, ud, cfg, inverse):
+        with torch.no_grad():
+            y, lad = _lib.rqs_elementwise_shared(x, uw, uh, ud, cfg, inverse, allow_grad=True)
+        ctx.save_for_backward(x, uw, uh, ud)
+        ctx.cfg, ctx.inverse = cfg, inverse
+        return y, lad.reshape(lad.shape[0], -1).sum(1)
+
+    @staticmethod
+    def backward(ctx, gy, glad):
+        x, uw, uh, ud = ctx.saved_tensors
+        gx, gw, gh, gd = _lib.rqs_shared_bwd(x, uw, uh, ud, gy, glad, ctx.cfg, ctx.inverse)
+        return gx, gw, gh, gd, None, None
+
+
+def rqs_shared(x, uw, uh, ud, cfg, inverse=False):
+    """(y, logabsdet[B]) of the batch-shared spline, differentiable."""
+    if cfg.num_bins in _lib.SHARED_BWD_BINS:
+        return RqsSharedFn.apply(x, uw, uh, ud, cfg, inverse)
+    y, lad = rqs_spline(x, uw, uh, ud, cfg, inverse)           # any K: dense expansion
+    return y, lad.reshape(lad.shape[0], -1).sum(1)
+
+
+def rqs_packed(x, params, cfg, inverse=False):
+    """(y, logabsdet[B]) of the conditional spline on packed conditioner output, differentiable."""
+    if cfg.num_bins <= 64:
+        return RqsPackedFn.apply(x, params, cfg, inverse)
+    raise NotImplementedError("spline VJP kernel covers up to 64 bins")
+
+
 def needs_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 

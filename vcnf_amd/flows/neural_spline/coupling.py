@@ -72,7 +72,7 @@ class PiecewiseRationalQuadraticCDF(Flow):
                 tuple(self.unnormalized_widths.shape[:-1]), tuple(inputs.shape)))
         splines._check_bins(self.num_bins, self.min_bin_width, self.min_bin_height)
         if autograd.needs_grad(inputs, *self.logits()):
-            out, lad = autograd.rqs_spline(inputs, *self.logits(), self._cfg(), inverse=inverse)
+            return autograd.rqs_shared(inputs, *self.logits(), self._cfg(), inverse=inverse)
         else:
             # one logit row per position, shared by the batch: read in place (no [B, ...] expansion)
             out, lad = _lib.rqs_elementwise_shared(inputs, *self.logits(), self._cfg(), inverse)
@@ -195,6 +195,19 @@ class PiecewiseRationalQuadraticCoupling(Flow):
             return net.trunk(first, context)
         return net(first, context) if context is not None else net(first)
 
+    def _split_index(self, device):
+        """(gather, scatter) int32 index vectors of the channel partition: gathered = inputs[:, g]
+        lists the identity features first, then the transform features; scattered = parts[:, s]
+        puts them back.  Both directions are the HIP column-gather kernel (and each is the
+        other's VJP), instead of two advanced-indexing gathers and two index_put scatters."""
+        key = ('split', str(device), self.identity_features.data_ptr(), self.identity_features._version)
+        hit = self._i32.get(key)
+        if hit is None:
+            g = torch.cat([self.identity_features, self.transform_features]).to(device)
+            hit = (g.to(torch.int32).contiguous(), torch.argsort(g).to(torch.int32).contiguous())
+            self._i32[key] = hit
+        return hit
+
     def _needs_grad(self, inputs, context):
         if not torch.is_grad_enabled():
             return False
@@ -203,29 +216,24 @@ class PiecewiseRationalQuadraticCoupling(Flow):
         return any(p.requires_grad for p in self.parameters())
 
     def _run_differentiable(self, inputs, context, sampling):
-        """Training path (coupling.py:70-125 as written there): gather / conditioner /
-        scatter are PyTorch ops, the splines and their gradients are the HIP kernels of
-        vcnf_amd.autograd."""
-        from ... import autograd
-        k = self.num_bins
-        xi = inputs[:, self.identity_features]
-        xt = inputs[:, self.transform_features]
-        lad_i = 0.0
+        """Training path (coupling.py:70-125 as written there): gather / conditioner / scatter are
+        PyTorch ops; the two spline families and their gradients are HIP kernels that read the
+        conditioner output and the shared logits in place (vcnf_amd.autograd)."""
+        gather, scatter = self._split_index(inputs.device)
+        parts = autograd.PermuteFn.apply(inputs, gather, scatter)
+        xi = parts[:, :self.num_identity_features].contiguous()
+        xt = parts[:, self.num_identity_features:].contiguous()
+        lad = 0.0
         uncond = self.unconditional_transform
         if sampling and uncond is not None:
-            xi, lad_e = autograd.rqs_spline(xi, *uncond.logits(), self._cfg(False), inverse=True)
-            lad_i = lad_e.sum(dim=1)
+            xi, lad = uncond.inverse(xi)
         params = self.transform_net(xi, context) if context is not None else self.transform_net(xi)
-        p = params.reshape(inputs.shape[0], self.num_transform_features, -1)
-        yt, lad_e = autograd.rqs_spline(xt, p[..., :k], p[..., k:2 * k], p[..., 2 * k:], self._cfg(True),
-                                        inverse=sampling)
-        lad = lad_e.sum(dim=1) + lad_i
+        yt, lad_t = autograd.rqs_packed(xt, params, self._cfg(True), inverse=sampling)
+        lad = lad + lad_t
         if (not sampling) and uncond is not None:
-            xi, lad_e = autograd.rqs_spline(xi, *uncond.logits(), self._cfg(False), inverse=False)
-            lad = lad + lad_e.sum(dim=1)
-        out = torch.empty_like(inputs)
-        out[:, self.identity_features] = xi
-        out[:, self.transform_features] = yt
+            xi, lad_i = uncond.forward(xi)
+            lad = lad + lad_i
+        out = autograd.PermuteFn.apply(torch.cat([xi, yt], dim=1), scatter, gather)
         return out, lad
 
     def _run_image(self, inputs, context, sampling):
@@ -243,13 +251,11 @@ class PiecewiseRationalQuadraticCoupling(Flow):
             xi, lad = uncond.inverse(xi)
         params = self.transform_net(xi, context) if context is not None else self.transform_net(xi)
         if grad:
-            b, c, h, w = xt.shape
-            p = params.reshape(b, c, -1, h, w).permute(0, 1, 3, 4, 2)
-            yt, le = autograd.rqs_spline(xt.contiguous(), p[..., :k], p[..., k:2 * k], p[..., 2 * k:],
-                                         self._cfg(True), inverse=sampling)
+            yt, le = autograd.rqs_packed(xt.contiguous(), params, self._cfg(True), inverse=sampling)
+            lad = lad + le
         else:
             yt, le = _lib.rqs_elementwise_image(xt, params, self._cfg(True), sampling)
-        lad = lad + le.sum(dim=(1, 2, 3))
+            lad = lad + le.sum(dim=(1, 2, 3))
         if (not sampling) and uncond is not None:
             xi, l2 = uncond.forward(xi)
             lad = lad + l2
