@@ -91,6 +91,22 @@ int vcnf_rqs_elementwise_strided_f32(const float* x, const float* uw, const floa
                                      const vcnf_rqs_cfg* cfg, int inverse, int32_t* bad_discriminant,
                                      void* stream);
 
+/* Whole AffineCouplingBlock on x[B, features] in one launch when the conditioner is an MLP with two
+ * hidden layers of equal width: Linear(c_in, hidden), LeakyReLU, Linear(hidden, hidden), LeakyReLU,
+ * Linear(hidden, n_out), n_out = 2*d_t (interleaved shift, scale) or d_t (scale map NONE).
+ * Replaces flows/affine/coupling.py:247-258 with :113-168, reshape.py:25-29, :50-55 and
+ * nets/mlp.py:30-58 for that case.  The conditioner reads x[:, cond_off : cond_off + c_in], the
+ * features [t_off, t_off + d_t) are transformed, the rest is copied.  hidden in {32, 64, 128},
+ * c_in <= 64, n_out <= 128.  wpack: vcnf_affine_layer_fused_pack_floats(...) floats in the
+ * fragment order documented in vcnf_amd/fused_affine.py. */
+int vcnf_affine_layer_fused_supported(int32_t c_in, int32_t hidden, int32_t n_out, int32_t features);
+int64_t vcnf_affine_layer_fused_pack_floats(int32_t c_in, int32_t hidden, int32_t n_out);
+int vcnf_affine_layer_fused_f32(const float* x, float* y, float* logdet, int64_t batch, int32_t features,
+                                int32_t cond_off, int32_t c_in, int32_t t_off, int32_t d_t,
+                                int32_t hidden, float leaky_slope, int scale_map,
+                                const float* wpack, int64_t wpack_floats,
+                                int inverse, int ld_mode, float ld_sign, void* stream);
+
 /* Vector-Jacobian product of vcnf_rqs_elementwise_f32 (training path; the reference
  * obtains it from autograd over utils/splines.py:88-193).  Inputs as the forward call
  * plus the upstream gradients g_y[n], g_logabsdet[n]; outputs g_x[n] and dense

@@ -809,3 +809,49 @@ def test_g17_image_rqs_coupling(hip, tag):
         err = (back - x).abs()
         assert float(err.mean()) < 2e-5 and float(err.max()) < 2e-2 and float((ld1 + ld2).abs().mean()) < 1e-3
     nf.check_discriminant()
+
+
+# ---------------------------------------------------------------- fused affine coupling layer
+@pytest.mark.parametrize("d,hidden,mode,sm", [
+    (2, 32, "channel", "exp"), (32, 64, "channel", "exp"), (32, 64, "channel_inv", "sigmoid"),
+    (33, 32, "channel_inv", "sigmoid_inv"), (75, 128, "channel", "noscale"), (128, 128, "channel", "exp"),
+    (9, 64, "channel_inv", "exp")])
+@pytest.mark.parametrize("batch", [1, 77, 4096])
+def test_fused_affine_layer_vs_three_step_path_and_oracle(hip, d, hidden, mode, sm, batch):
+    """One-kernel AffineCouplingBlock (MLP conditioner on the fp32 matrix instruction) against the
+    three-step path (torch GEMMs + affine kernel) and against the oracle in fp64."""
+    from vcnf_amd import fused_affine
+    torch.manual_seed(d * 7 + hidden)
+    head = d - d // 2
+    cin, cout = (head, d - head) if mode == "channel" else (d - head, head)
+    scale = sm != "noscale"
+    blk = nf.flows.AffineCouplingBlock(nf.nets.MLP([cin, hidden, hidden, (2 if scale else 1) * cout], leaky=0.1),
+                                       scale=scale, scale_map=sm if scale else "exp", split_mode=mode)
+    with torch.no_grad():
+        blk.flows[1].param_map.net[4].weight.mul_(0.5)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    blk = blk.cuda()
+    x = torch.randn(batch, d)
+    assert fused_affine.eligible(blk, dev(x))
+    sd64 = {k: v.double() for k, v in sd.items()}
+    ora = OL.AffineCouplingBlock(lambda z: ON.mlp(sd64, "flows.1.param_map.", z, 0.1), scale=scale,
+                                 scale_map=sm if scale else "exp", split_mode=mode)
+    with torch.no_grad():
+        for dirn in ("forward", "inverse"):
+            blk.fused = True
+            z1, ld1 = getattr(blk, dirn)(dev(x))
+            blk.fused = False
+            z2, ld2 = getattr(blk, dirn)(dev(x))
+            want_z, want_ld = getattr(ora, dirn)(x.double())
+            assert_close(z1, want_z, what="fused z " + dirn, rtol=2e-5, atol=2e-5)
+            assert_close(z2, want_z, what="three-step z " + dirn, rtol=2e-5, atol=2e-5)
+            if scale:
+                assert_close(ld1, want_ld, what="fused ld " + dirn, rtol=2e-5, atol=2e-5 * max(1, cout))
+            else:
+                assert not ld1.any()
+        # accumulate-into form used by NormalizingFlow
+        blk.fused = True
+        lq = torch.full((batch,), 0.25, device="cuda")
+        z3 = blk.inverse_into(dev(x), lq)
+        zi, ldi = blk.inverse(dev(x))
+        assert torch.equal(z3, zi) and torch.allclose(lq, 0.25 + ldi, rtol=1e-6, atol=1e-6)

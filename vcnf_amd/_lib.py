@@ -40,6 +40,10 @@ PROTOTYPES = {
                                           ctypes.POINTER(RqsCfg), _INT, _P, _P], _INT),
     "vcnf_rqs_elementwise_bwd_f32": ([_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _I64,
                                       ctypes.POINTER(RqsCfg), _INT, _P], _INT),
+    "vcnf_affine_layer_fused_supported": ([_I32, _I32, _I32, _I32], _INT),
+    "vcnf_affine_layer_fused_pack_floats": ([_I32, _I32, _I32], _I64),
+    "vcnf_affine_layer_fused_f32": ([_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _INT, _P, _I64,
+                                     _INT, _INT, _F32, _P], _INT),
     "vcnf_rqs_packed_bwd_f32": ([_P, _P, _I64, _I64, _P, _P, _P, _P, _I64, ctypes.POINTER(RqsCfg), _INT, _P], _INT),
     "vcnf_rqs_shared_bwd_groups": ([_I64, _I64], _I64),
     "vcnf_rqs_shared_bwd_f32": ([_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _I64,
@@ -420,6 +424,26 @@ def affine_coupling(z, param, t_off, d_t, scale_map, inverse, logdet=None, sign=
                                             int(t_off), int(d_t), int(scale_map), int(bool(inverse)),
                                             mode, float(sign), _stream())
     _check(st, "vcnf_affine_coupling_f32")
+    return out, logdet
+
+
+def affine_layer_fused(z, wpack, cond_off, c_in, t_off, d_t, hidden, slope, scale_map, inverse, logdet=None,
+                       sign=1.0):
+    """Whole AffineCouplingBlock (MLP conditioner included) in one kernel; csrc/fused_affine.hip."""
+    dev = require_device(z, wpack, logdet)
+    z = z.contiguous()
+    b, d = z.shape
+    out = torch.empty_like(z)
+    mode = LD_ACCUM
+    if logdet is None:
+        mode = LD_STORE
+        logdet = (torch.empty if scale_map != SCALE_NONE else torch.zeros)(b, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = lib().vcnf_affine_layer_fused_f32(_ptr(z), _ptr(out), _ptr(logdet) if scale_map != SCALE_NONE else None,
+                                               b, d, int(cond_off), int(c_in), int(t_off), int(d_t), int(hidden),
+                                               float(slope), int(scale_map), _ptr(wpack), wpack.numel(),
+                                               int(bool(inverse)), mode, float(sign), _stream())
+    _check(st, "vcnf_affine_layer_fused_f32")
     return out, logdet
 
 

@@ -1,0 +1,247 @@
+// Fused affine coupling layer (AffineCouplingBlock with an MLP conditioner of two hidden
+// layers) for MI355X: conditioner + affine transform + log|det| in one launch.
+//
+// Reference path per layer (flows/affine/coupling.py:113-168, :247-258, nets/mlp.py:30-58):
+// chunk, three Linear + two LeakyReLU kernels, slicing of the interleaved (shift, scale)
+// parameters, the elementwise map, a row sum, a concatenation.  Config C2 (D = 32, MLP
+// 16-64-64-32, 8 layers) spends its time in launch gaps and in round trips of [B, 64]
+// activations through HBM.  Here a layer reads x once and writes y once.
+//
+// Work split: a wave owns 16 samples from input to output; nothing is exchanged between waves.
+// The MLP runs on v_mfma_f32_16x16x4_f32 (exact fp32 products) with the weights as the A operand
+// and the wave's 16 samples as the 16 columns of the B operand.  A layer's accumulators ARE the
+// next layer's B operand: accumulator register r of row block pb holds unit 16 pb + 4 q + r of
+// sample (lane & 15) in lane group q = lane >> 4, so the next layer consumes k-step j = 4 pb + r
+// straight from registers and its weights are packed on the host in that k order
+// (vcnf_amd/fused_affine.py).  Weights (<= 0.2 MB, hot in L1/L2) are fetched with one 16-byte
+// buffer load per four matrix instructions.  The last layer's row order puts shift and scale of
+// a feature side by side in one lane (rows 4 q + r: r = 0, 1 -> feature 8 ob + 2 q, r = 2, 3 ->
+// the next one), which is exactly the reference's interleaved parameter layout.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/vcnf_hip.h"
+#include "fused_common.hpp"
+
+namespace vcnf {
+
+struct FusedAffineArgs {
+  const float* x;
+  float* y;
+  float* logdet;
+  const float* wpack;
+  unsigned wpack_bytes;
+  long long B;
+  int D, c_in, cond_off, d_t, t_off;
+  int KI;            // first-layer k-steps = ceil(c_in / 4)
+  int OB;            // output row blocks = ceil(n_out / 16)
+  int scale_map, inverse, ld_mode;
+  float ld_sign, slope;
+  int off_b1, off_w2, off_b2, off_w3, off_b3;   // float offsets inside wpack (w1 at 0)
+};
+
+__device__ __forceinline__ float aff_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
+
+// One transformed element: same arithmetic as affine_coupling_kernel (coupling.py:124-136, :150-162).
+__device__ __forceinline__ float affine_apply(float v, float shift, float sc, int scale_map, int inverse, float& acc) {
+  if (scale_map == VCNF_SCALE_EXP) {
+    if (inverse) { acc -= sc; return (v - shift) * expf(-sc); }
+    acc += sc;
+    return v * expf(sc) + shift;
+  }
+  const float sg = aff_sigmoid(sc + 2.f);
+  const float lg = logf(sg);
+  const bool divide = (scale_map == VCNF_SCALE_SIGMOID) != (inverse != 0);
+  acc += divide ? -lg : lg;
+  if (inverse) return divide ? (v - shift) / sg : (v - shift) * sg;
+  return divide ? v / sg + shift : v * sg + shift;
+}
+
+constexpr int kFABlock = 256;          // 4 waves x 16 samples
+
+// KIG: first-layer k-step groups of four (c_in <= 16 KIG); HB: hidden row blocks (hidden = 16 HB,
+// both hidden layers); OBM: most output row blocks (2 d_t or d_t <= 16 OBM).
+template <int KIG, int HB, int OBM>
+__global__ __launch_bounds__(kFABlock) void fused_affine_layer_kernel(const FusedAffineArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m16 = lane & 15;
+  const int q = lane >> 4;
+  const int D = a.D;
+  const int XS = D + 1;                                   // odd-ish row stride: rows of a wave spread over banks
+  float* xs = smem + wave * 16 * XS;                      // this wave's 16 rows
+  const __amdgpu_buffer_rsrc_t wr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpack), 0, a.wpack_bytes, 0x00020000);
+  const int voff = lane * 16;
+  const int qoff = q * 16;
+  const bool scaled = a.scale_map != VCNF_SCALE_NONE;
+
+  const long long ntiles = (a.B + 63) / 64;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long b0 = tile * 64 + wave * 16;
+    const int rows = (int)max(0LL, min(16LL, a.B - b0));
+    __syncthreads();
+    for (int e = lane; e < 16 * D; e += 64) {
+      const int r = e / D, c = e - r * D;
+      xs[r * XS + c] = r < rows ? a.x[(b0 + r) * D + c] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- layer 1: natural k order, k-step s of lane group q reads input 4 s + q
+    floatx4 h1[HB];
+    {
+      float xin[4 * KIG];
+#pragma unroll
+      for (int s = 0; s < 4 * KIG; ++s) {
+        const int c = 4 * s + q;
+        xin[s] = (s < a.KI && c < a.c_in) ? xs[m16 * XS + a.cond_off + c] : 0.f;
+      }
+#pragma unroll
+      for (int nb = 0; nb < HB; ++nb) {
+        floatx4 acc = wload(wr, qoff, 4 * (a.off_b1 + 16 * nb));
+#pragma unroll
+        for (int g = 0; g < KIG; ++g) {
+          const floatx4 w = wload(wr, voff, 4 * ((nb * KIG + g) * 256));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc = mfma4(w[i], xin[4 * g + i], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[nb][r] = acc[r] > 0.f ? acc[r] : a.slope * acc[r];   // LeakyReLU, mlp.py:33
+      }
+    }
+    // ---- layer 2: chained k order (k-step 4 pb + r <- accumulator r of row block pb)
+    floatx4 h2[HB];
+#pragma unroll
+    for (int nb = 0; nb < HB; ++nb) {
+      floatx4 acc = wload(wr, qoff, 4 * (a.off_b2 + 16 * nb));
+#pragma unroll
+      for (int pb = 0; pb < HB; ++pb) {
+        const floatx4 w = wload(wr, voff, 4 * (a.off_w2 + (nb * HB + pb) * 256));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma4(w[r], h1[pb][r], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h2[nb][r] = acc[r] > 0.f ? acc[r] : a.slope * acc[r];
+    }
+    // ---- layer 3 + affine map on the lane's features
+    float ld = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < OBM; ++ob) {
+      if (ob < a.OB) {
+        floatx4 acc = wload(wr, qoff, 4 * (a.off_b3 + 16 * ob));
+#pragma unroll
+        for (int pb = 0; pb < HB; ++pb) {
+          const floatx4 w = wload(wr, voff, 4 * (a.off_w3 + (ob * HB + pb) * 256));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = mfma4(w[r], h2[pb][r], acc);
+        }
+        if (scaled) {
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const int f = 8 * ob + 2 * q + pr;              // rows 4 q + 2 pr (shift), + 1 (scale)
+            if (f < a.d_t) {
+              float* pz = xs + m16 * XS + a.t_off + f;
+              *pz = affine_apply(*pz, acc[2 * pr], acc[2 * pr + 1], a.scale_map, a.inverse, ld);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int f = 16 * ob + 4 * q + r;
+            if (f < a.d_t) {
+              float* pz = xs + m16 * XS + a.t_off + f;
+              *pz = a.inverse ? *pz - acc[r] : *pz + acc[r];  // coupling.py:139-141 / :165-167
+            }
+          }
+        }
+      }
+    }
+    if (a.logdet) {
+      ld += __shfl_xor(ld, 16, 64);
+      ld += __shfl_xor(ld, 32, 64);
+      if (q == 0 && m16 < rows) {
+        const float o = a.ld_sign * ld;
+        a.logdet[b0 + m16] = a.ld_mode ? a.logdet[b0 + m16] + o : o;
+      }
+    }
+    __syncthreads();
+    for (int e = lane; e < rows * D; e += 64) {
+      const int r = e / D, c = e - r * D;
+      a.y[(b0 + r) * D + c] = xs[r * XS + c];
+    }
+  }
+}
+
+template <int KIG, int HB, int OBM>
+static int launch_fa(const FusedAffineArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)4 * 16 * (a.D + 1) * sizeof(float);
+  if (lds > 64 * 1024) return VCNF_ERR_SHAPE;
+  const long long ntiles = (a.B + 63) / 64;
+  const long long cap = 256 * 8;
+  dim3 grid((unsigned)(ntiles < cap ? ntiles : cap));
+  hipLaunchKernelGGL((fused_affine_layer_kernel<KIG, HB, OBM>), grid, dim3(kFABlock), lds, st, a);
+  return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
+}
+
+static bool fa_shape_ok(int c_in, int hidden, int n_out, int features) {
+  if (c_in < 1 || c_in > 64 || n_out < 1 || n_out > 128) return false;
+  if (hidden != 32 && hidden != 64 && hidden != 128) return false;
+  if (features < 2 || features > 1023) return false;
+  return true;
+}
+
+}  // namespace vcnf
+
+using namespace vcnf;
+
+extern "C" int vcnf_affine_layer_fused_supported(int32_t c_in, int32_t hidden, int32_t n_out, int32_t features) {
+  return fa_shape_ok(c_in, hidden, n_out, features) ? 1 : 0;
+}
+
+extern "C" int64_t vcnf_affine_layer_fused_pack_floats(int32_t c_in, int32_t hidden, int32_t n_out) {
+  if (!fa_shape_ok(c_in, hidden, n_out, 2)) return 0;
+  const int KIG = c_in <= 16 ? 1 : 4, HB = hidden / 16, OB = (n_out + 15) / 16;
+  return (int64_t)HB * KIG * 256 + 16 * HB + (int64_t)HB * HB * 256 + 16 * HB + (int64_t)OB * HB * 256 + 16 * OB;
+}
+
+extern "C" int vcnf_affine_layer_fused_f32(const float* x, float* y, float* logdet, int64_t batch, int32_t features,
+                                           int32_t cond_off, int32_t c_in, int32_t t_off, int32_t d_t,
+                                           int32_t hidden, float leaky_slope, int scale_map,
+                                           const float* wpack, int64_t wpack_floats,
+                                           int inverse, int ld_mode, float ld_sign, void* stream) {
+  const int n_out = scale_map == VCNF_SCALE_NONE ? d_t : 2 * d_t;
+  if (batch < 0 || !fa_shape_ok(c_in, hidden, n_out, features)) return VCNF_ERR_SHAPE;
+  if (cond_off < 0 || t_off < 0 || cond_off + c_in > features || t_off + d_t > features) return VCNF_ERR_SHAPE;
+  if (scale_map < VCNF_SCALE_EXP || scale_map > VCNF_SCALE_NONE) return VCNF_ERR_UNSUPPORTED;
+  if (ld_mode != VCNF_LD_STORE && ld_mode != VCNF_LD_ACCUM) return VCNF_ERR_UNSUPPORTED;
+  if (wpack_floats != vcnf_affine_layer_fused_pack_floats(c_in, hidden, n_out)) return VCNF_ERR_SHAPE;
+  if (batch == 0) return VCNF_OK;
+  if (!x || !y || !wpack || (scale_map != VCNF_SCALE_NONE && !logdet)) return VCNF_ERR_NULL;
+  FusedAffineArgs a;
+  a.x = x; a.y = y; a.logdet = logdet; a.wpack = wpack; a.wpack_bytes = (unsigned)(wpack_floats * 4);
+  a.B = batch; a.D = features; a.c_in = c_in; a.cond_off = cond_off; a.d_t = d_t; a.t_off = t_off;
+  a.KI = (c_in + 3) / 4; a.OB = (n_out + 15) / 16;
+  a.scale_map = scale_map; a.inverse = inverse ? 1 : 0; a.ld_mode = ld_mode; a.ld_sign = ld_sign; a.slope = leaky_slope;
+  const int KIG = c_in <= 16 ? 1 : 4, HB = hidden / 16;
+  a.off_b1 = HB * KIG * 256;
+  a.off_w2 = a.off_b1 + 16 * HB;
+  a.off_b2 = a.off_w2 + HB * HB * 256;
+  a.off_w3 = a.off_b2 + 16 * HB;
+  a.off_b3 = a.off_w3 + a.OB * HB * 256;
+  hipStream_t st = (hipStream_t)stream;
+  const bool small_out = a.OB <= 2;
+#define VCNF_FA(KIG_, HB_)                                                              \
+  return small_out ? launch_fa<KIG_, HB_, 2>(a, st) : launch_fa<KIG_, HB_, 8>(a, st);
+  if (KIG == 1) {
+    if (HB == 2) { VCNF_FA(1, 2) }
+    if (HB == 4) { VCNF_FA(1, 4) }
+    VCNF_FA(1, 8)
+  }
+  if (HB == 2) { VCNF_FA(4, 2) }
+  if (HB == 4) { VCNF_FA(4, 4) }
+  VCNF_FA(4, 8)
+#undef VCNF_FA
+}

@@ -8,7 +8,7 @@ from torch import nn
 
 from ..base import Flow
 from ..reshape import Split, Merge
-from ... import _lib, autograd
+from ... import _lib, autograd, fused_affine
 
 
 def _scale_code(scale, scale_map):
@@ -138,6 +138,9 @@ class AffineCouplingBlock(Flow):
         self.flows = nn.ModuleList([Split(split_mode), AffineCoupling(param_map, scale, scale_map),
                                     Merge(split_mode)])
         self.split_mode = split_mode
+        # single-kernel layer when the conditioner is an MLP with two equal hidden layers on [B, D]
+        # inputs (fused_affine.eligible); False forces the three-step path
+        self.fused = True
 
     def _run(self, z, inverse, log_q=None, sign=1.0):
         if self.split_mode not in ('channel', 'channel_inv'):
@@ -152,6 +155,10 @@ class AffineCouplingBlock(Flow):
             return out, (ld if sign == 1.0 else sign * ld)
         core = self.flows[1]
         code = _scale_code(core.scale, core.scale_map)
+        if (self.fused and not autograd.needs_grad(z, log_q, *core.param_map.parameters())
+                and fused_affine.eligible(self, z)):
+            # conditioner + affine map + log|det| in one kernel (csrc/fused_affine.hip)
+            return fused_affine.run(self, z, code, inverse, log_q, sign)
         c = z.shape[1]
         head = c - c // 2                              # chunk(2): first chunk has ceil(C/2) channels
         if self.split_mode == 'channel':

@@ -1,0 +1,111 @@
+"""Host side of the fused affine-coupling-layer kernel (csrc/fused_affine.hip): eligibility,
+weight packing (matrix-core fragment order, cached per parameter version) and launch.
+
+Fragment order (v_mfma_f32_16x16x4_f32, weights as the A operand): for output row block nb and a
+group of four k-steps the 64 lanes hold float4 W[16 nb + (lane & 15)][k(step, lane >> 4)].  The
+first layer reads the input tile, k = 4 step + q; the other two consume the previous layer's
+accumulators, k = 16 pb + 4 q + r for step 4 pb + r.  Biases are stored per row block as
+[q][r] -> bias[16 nb + 4 q + r], the accumulator row order.
+"""
+import torch
+from torch import nn
+
+from . import _lib
+
+
+def _linears(mlp):
+    """(linears, slope) when ``mlp`` is Linear, LeakyReLU, Linear, LeakyReLU, Linear; else None."""
+    from .nets.mlp import MLP
+    if type(mlp) is not MLP:
+        return None
+    mods = list(mlp.net)
+    if len(mods) != 5 or not all(isinstance(mods[i], nn.Linear) for i in (0, 2, 4)):
+        return None
+    if not all(isinstance(mods[i], nn.LeakyReLU) for i in (1, 3)) or mods[1].negative_slope != mods[3].negative_slope:
+        return None
+    return [mods[0], mods[2], mods[4]], float(mods[1].negative_slope)
+
+
+def eligible(block, z):
+    if z.dim() != 2 or block.split_mode not in ('channel', 'channel_inv'):
+        return False
+    core = block.flows[1]
+    got = _linears(core.param_map)
+    if got is None:
+        return False
+    (l1, l2, l3), _ = got
+    if l1.out_features != l2.in_features or l2.out_features != l1.out_features or l3.in_features != l2.out_features:
+        return False
+    return bool(_lib.lib().vcnf_affine_layer_fused_supported(l1.in_features, l1.out_features, l3.out_features,
+                                                             z.shape[1]))
+
+
+def _pack_first(w, hb, kig):
+    dev = w.device
+    nb = torch.arange(hb, device=dev).view(-1, 1, 1, 1)
+    g = torch.arange(kig, device=dev).view(1, -1, 1, 1)
+    lane = torch.arange(64, device=dev).view(1, 1, -1, 1)
+    i = torch.arange(4, device=dev).view(1, 1, 1, -1)
+    rows = (16 * nb + (lane & 15)).expand(hb, kig, 64, 4)
+    cols = (4 * (4 * g + i) + (lane >> 4)).expand(hb, kig, 64, 4)
+    ok = cols < w.shape[1]
+    vals = w[rows, torch.where(ok, cols, torch.zeros_like(cols))]
+    return torch.where(ok, vals, torch.zeros((), device=dev, dtype=w.dtype)).reshape(-1)
+
+
+def _pack_chained(w, nb_out, hb):
+    """w [n_out, 16 hb] (rows beyond n_out are zero) -> [nb][pb][lane][r]."""
+    dev = w.device
+    nb = torch.arange(nb_out, device=dev).view(-1, 1, 1, 1)
+    pb = torch.arange(hb, device=dev).view(1, -1, 1, 1)
+    lane = torch.arange(64, device=dev).view(1, 1, -1, 1)
+    r = torch.arange(4, device=dev).view(1, 1, 1, -1)
+    rows = (16 * nb + (lane & 15)).expand(nb_out, hb, 64, 4)
+    cols = (16 * pb + 4 * (lane >> 4) + r).expand(nb_out, hb, 64, 4)
+    ok = rows < w.shape[0]
+    vals = w[torch.where(ok, rows, torch.zeros_like(rows)), cols]
+    return torch.where(ok, vals, torch.zeros((), device=dev, dtype=w.dtype)).reshape(-1)
+
+
+def _pack_bias(b, blocks):
+    out = torch.zeros(16 * blocks, dtype=b.dtype, device=b.device)
+    out[:b.numel()] = b
+    return out
+
+
+def pack(l1, l2, l3):
+    hb = l1.out_features // 16
+    kig = 1 if l1.in_features <= 16 else 4
+    ob = (l3.out_features + 15) // 16
+    parts = [_pack_first(l1.weight.detach(), hb, kig), _pack_bias(l1.bias.detach(), hb),
+             _pack_chained(l2.weight.detach(), hb, hb), _pack_bias(l2.bias.detach(), hb),
+             _pack_chained(l3.weight.detach(), ob, hb), _pack_bias(l3.bias.detach(), ob)]
+    buf = torch.cat(parts).contiguous()
+    want = int(_lib.lib().vcnf_affine_layer_fused_pack_floats(l1.in_features, l1.out_features, l3.out_features))
+    assert buf.numel() == want, (buf.numel(), want)
+    return buf
+
+
+def packed_weights(block):
+    (l1, l2, l3), slope = _linears(block.flows[1].param_map)
+    params = (l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias)
+    key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+    cache = block.__dict__.setdefault('_fused_affine_pack', {})
+    if cache.get('key') != key:
+        cache['key'] = key
+        cache['buf'] = pack(l1, l2, l3)
+    return cache['buf'], (l1, l2, l3), slope
+
+
+def run(block, z, code, inverse, log_q=None, sign=1.0):
+    """Whole AffineCouplingBlock on [B, D] in one launch; same (out, log_det) contract as the
+    three-step path of AffineCouplingBlock._run."""
+    buf, (l1, _, l3), slope = packed_weights(block)
+    c = z.shape[1]
+    head = c - c // 2
+    if block.split_mode == 'channel':
+        cond_off, t_off, d_t = 0, head, c - head
+    else:
+        cond_off, t_off, d_t = head, 0, head
+    return _lib.affine_layer_fused(z, buf, cond_off, l1.in_features, t_off, d_t, l1.out_features, slope, code,
+                                   inverse, logdet=log_q, sign=sign)
