@@ -855,3 +855,32 @@ def test_fused_affine_layer_vs_three_step_path_and_oracle(hip, d, hidden, mode, 
         z3 = blk.inverse_into(dev(x), lq)
         zi, ldi = blk.inverse(dev(x))
         assert torch.equal(z3, zi) and torch.allclose(lq, 0.25 + ldi, rtol=1e-6, atol=1e-6)
+
+
+# ---------------------------------------------------------------- HIP-graph capture of the evaluation loops
+@pytest.mark.parametrize("kind", ["c3", "c1"])
+def test_graphed_flow_replays_match_eager(hip, kind):
+    """log_prob / sample_from captured into a HIP graph (one launch per call) give the eager
+    results bit for bit, for fresh inputs and after an in-place weight update."""
+    torch.manual_seed(3)
+    if kind == "c3":
+        model, ctx_dim, d, b = _c3_model(layers=4).cuda(), 16, 64, 1000
+    else:
+        model, ctx_dim, d, b = _affine_model(4, 2, [1, 32, 32, 2]).cuda(), None, 2, 4096
+    g = nf.GraphedFlow(model, batch=b, context_features=ctx_dim)
+    for trial in range(3):
+        x, eps = torch.randn(b, d, device="cuda"), torch.randn(b, d, device="cuda")
+        ctx = torch.randn(b, ctx_dim, device="cuda") if ctx_dim else None
+        kw = {"context": ctx} if ctx_dim else {}
+        if trial == 2:
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(0.01 * torch.randn_like(p))
+            g.refresh()
+        with torch.no_grad():
+            want_lp = model.log_prob(x, **kw)
+            want_z, want_lq = model.sample_from(eps, **kw)
+        lp = g.log_prob(x, ctx).clone()
+        z, lq = g.sample_from(eps, ctx)
+        assert torch.equal(lp, want_lp) and torch.equal(z, want_z) and torch.equal(lq, want_lq), trial
+    nf.check_discriminant()

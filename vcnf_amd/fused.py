@@ -173,8 +173,9 @@ def precision_of(coupling):
 
 
 def packed_weights(coupling):
-    """Cached packed buffer; rebuilt when any conditioner parameter (or the matrix
-    precision) changed."""
+    """Cached packed buffer; refreshed when any conditioner parameter (or the matrix precision)
+    changed.  A refresh of the same size rewrites the existing device buffer in place, so a
+    captured HIP graph that holds its address (vcnf_amd.graphs) sees the new weights."""
     net = coupling.transform_net
     prec = precision_of(coupling)
     key = (prec,) + tuple((p.data_ptr(), p._version) for p in net.parameters())
@@ -182,6 +183,9 @@ def packed_weights(coupling):
     if cache is None or cache[0] != key:
         with torch.no_grad():
             buf = pack_layer(net, coupling.num_transform_features, coupling._transform_dim_multiplier(), prec)
+            if cache is not None and cache[1].shape == buf.shape and cache[1].device == buf.device:
+                cache[1].copy_(buf)
+                buf = cache[1]
         cache = (key, buf)
         coupling.__dict__['_fused_pack'] = cache
     return cache[1]

@@ -93,7 +93,12 @@ def packed_weights(block):
     cache = block.__dict__.setdefault('_fused_affine_pack', {})
     if cache.get('key') != key:
         cache['key'] = key
-        cache['buf'] = pack(l1, l2, l3)
+        buf = pack(l1, l2, l3)
+        old = cache.get('buf')
+        if old is not None and old.shape == buf.shape and old.device == buf.device:
+            old.copy_(buf)           # in place: a captured HIP graph keeps reading this address
+        else:
+            cache['buf'] = buf
     return cache['buf'], (l1, l2, l3), slope
 
 
