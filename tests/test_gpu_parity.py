@@ -884,3 +884,42 @@ def test_graphed_flow_replays_match_eager(hip, kind):
         z, lq = g.sample_from(eps, ctx)
         assert torch.equal(lp, want_lp) and torch.equal(z, want_z) and torch.equal(lq, want_lq), trial
     nf.check_discriminant()
+
+
+# ---------------------------------------------------------------- fused RQS layer, d_id = d_t = 16 family
+@pytest.mark.parametrize("ctx_dim", [0, 16])
+@pytest.mark.parametrize("precision", ["fp16x3", "fp32"])
+def test_fused_rqs_layer_d32_family(hip, ctx_dim, precision):
+    """D = 32 (16 identity + 16 transformed features, H = 128, 2 blocks, 8 bins) takes the fused
+    kernels too; compared with the three-step path and with the oracle (fp32 and fp64)."""
+    torch.manual_seed(41 + ctx_dim)
+    lay = nf.flows.CoupledRationalQuadraticSpline(32, 2, 128, 8, reverse_mask=True,
+                                                  num_context_channels=ctx_dim or None)
+    with torch.no_grad():
+        for n, p in lay.named_parameters():
+            if "final_layer" in n:
+                p.normal_(0, 0.5)
+            if "unconditional" in n:
+                p.normal_(0, 0.5)
+    sd = {k: v.detach().clone() for k, v in lay.state_dict().items()}
+    lay = lay.cuda()
+    lay.prqct.fused_precision = precision
+    b = 777
+    x = 1.5 * torch.randn(b, 32)
+    ctx = torch.randn(b, 16) if ctx_dim else None
+    from vcnf_amd import fused
+    assert fused.eligible(lay.prqct, dev(ctx) if ctx_dim else None)
+    o32 = oracle_rqs_coupling(sd, "prqct.", 8, 3.0, 128)
+    o64 = oracle_rqs_coupling({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, "prqct.", 8, 3.0, 128)
+    with torch.no_grad():
+        for dirn in ("forward", "inverse"):
+            lay.prqct.fused = True
+            z, ld = getattr(lay, dirn)(dev(x), dev(ctx) if ctx_dim else None)
+            lay.prqct.fused = False
+            z2, ld2 = getattr(lay, dirn)(dev(x), dev(ctx) if ctx_dim else None)
+            w32 = getattr(o32, dirn)(x, ctx)
+            w64 = getattr(o64, dirn)(x.double(), ctx.double() if ctx_dim else None)
+            parity(z, w32[0], w64[0], what="fused z " + dirn)
+            parity(ld, w32[1], w64[1], rtol=1e-5, atol=2e-5, what="fused ld " + dirn)
+            parity(z2, w32[0], w64[0], what="split z " + dirn)
+    nf.check_discriminant()

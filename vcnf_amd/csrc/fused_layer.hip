@@ -302,15 +302,17 @@ static int launch_fused(const FusedArgs& a, int inverse, hipStream_t st) {
 
 using namespace vcnf;
 
-extern "C" int64_t vcnf_rqs_layer_fused_pack_floats(int32_t ctx_dim) {
-  return ctx_dim == 16 ? PackLayout<32, 32, 16, 128, 2, 8>::TOTAL : PackLayout<32, 32, 0, 128, 2, 8>::TOTAL;
+// shape family: d_id = d_t in {16, 32}, context 0 or 16 (hidden 128, 2 residual blocks, 8 bins, linear tails)
+extern "C" int64_t vcnf_rqs_layer_fused_pack_floats(int32_t d_id, int32_t d_t, int32_t ctx_dim) {
+  if (d_id != d_t || (d_id != 16 && d_id != 32) || (ctx_dim != 0 && ctx_dim != 16)) return 0;
+  if (d_id == 32) return ctx_dim == 16 ? PackLayout<32, 32, 16, 128, 2, 8>::TOTAL : PackLayout<32, 32, 0, 128, 2, 8>::TOTAL;
+  return ctx_dim == 16 ? PackLayout<16, 16, 16, 128, 2, 8>::TOTAL : PackLayout<16, 16, 0, 128, 2, 8>::TOTAL;
 }
 
 extern "C" int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t ctx_dim, int32_t hidden,
                                               int32_t num_blocks, int32_t num_bins, int32_t tails) {
   if (tails != VCNF_TAILS_LINEAR || num_bins != 8 || hidden != 128 || num_blocks != 2) return 0;
-  if (d_id == 32 && d_t == 32 && (ctx_dim == 16 || ctx_dim == 0)) return 1;
-  return 0;
+  return vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim) > 0 ? 1 : 0;
 }
 
 // VCNF_FUSED_KERNEL=v2|v3 selects an earlier work split of the fp16 split-half kernel (A/B timing);
@@ -324,13 +326,11 @@ static int fused_version() {
   return v;
 }
 
-static int launch_f16x3(const FusedArgs& a, int ctx_dim, int inverse, hipStream_t st) {
-  const int v = fused_version();
-  if (ctx_dim == 16)
-    return v == 2 ? launch_fused_v2_c16(a, inverse, st) : v == 3 ? launch_fused_v3_c16(a, inverse, st)
-                                                                 : launch_fused_v4_c16(a, inverse, st);
-  return v == 2 ? launch_fused_v2_c0(a, inverse, st) : v == 3 ? launch_fused_v3_c0(a, inverse, st)
-                                                               : launch_fused_v4_c0(a, inverse, st);
+static int launch_f16x3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+  const int v = d_id == 32 ? fused_version() : 4;      // the earlier work splits exist for d_id = 32 only
+  if (v == 4) return launch_fused_v4(a, d_id, ctx_dim, inverse, st);
+  if (ctx_dim == 16) return v == 2 ? launch_fused_v2_c16(a, inverse, st) : launch_fused_v3_c16(a, inverse, st);
+  return v == 2 ? launch_fused_v2_c0(a, inverse, st) : launch_fused_v3_c0(a, inverse, st);
 }
 
 extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, float* logdet,
@@ -372,12 +372,11 @@ extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, fl
   a.c.wh_scale = cfg->wh_scale;
   a.c.edge_logit = (float)log(exp(1.0 - (double)cfg->min_derivative) - 1.0);
   hipStream_t st = (hipStream_t)stream;
-  if (ctx_dim == 16) {
-    if (wpack_floats != PackLayout<32, 32, 16, 128, 2, 8>::TOTAL) return VCNF_ERR_SHAPE;
-    if (precision == VCNF_PREC_F16X3) return launch_f16x3(a, 16, inverse, st);
-    return launch_fused<32, 32, 16, 128, 2, 8, 2>(a, inverse, st);
-  }
-  if (wpack_floats != PackLayout<32, 32, 0, 128, 2, 8>::TOTAL) return VCNF_ERR_SHAPE;
-  if (precision == VCNF_PREC_F16X3) return launch_f16x3(a, 0, inverse, st);
-  return launch_fused<32, 32, 0, 128, 2, 8, 2>(a, inverse, st);
+  if (wpack_floats != vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim)) return VCNF_ERR_SHAPE;
+  if (precision == VCNF_PREC_F16X3) return launch_f16x3(a, d_id, ctx_dim, inverse, st);
+  if (d_id == 32)
+    return ctx_dim == 16 ? launch_fused<32, 32, 16, 128, 2, 8, 2>(a, inverse, st)
+                         : launch_fused<32, 32, 0, 128, 2, 8, 2>(a, inverse, st);
+  return ctx_dim == 16 ? launch_fused<16, 16, 16, 128, 2, 8, 2>(a, inverse, st)
+                       : launch_fused<16, 16, 0, 128, 2, 8, 2>(a, inverse, st);
 }

@@ -526,12 +526,12 @@ static int launch_v4(const FusedArgs& a, int inverse, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }
 
-int launch_fused_v4_c16(const FusedArgs& a, int inverse, hipStream_t st) {
-  return launch_v4<32, 32, 16, 128, 2, 8>(a, inverse, st);
-}
-
-int launch_fused_v4_c0(const FusedArgs& a, int inverse, hipStream_t st) {
-  return launch_v4<32, 32, 0, 128, 2, 8>(a, inverse, st);
+// Shape family of the fused fp16 split-half kernel: (d_id, d_t, ctx) with H = 128, 2 blocks, 8 bins.
+int launch_fused_v4(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+  if (d_id == 32) {
+    return ctx_dim == 16 ? launch_v4<32, 32, 16, 128, 2, 8>(a, inverse, st) : launch_v4<32, 32, 0, 128, 2, 8>(a, inverse, st);
+  }
+  return ctx_dim == 16 ? launch_v4<16, 16, 16, 128, 2, 8>(a, inverse, st) : launch_v4<16, 16, 0, 128, 2, 8>(a, inverse, st);
 }
 
 }  // namespace vcnf
