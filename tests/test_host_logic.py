@@ -239,3 +239,18 @@ def test_lu_linear_permute_matches_reference_fixture(d):
     z, ld = lay.inverse(x.clone().requires_grad_())
     (z.sum() + ld.sum()).backward()
     assert all(p.grad is not None for p in lay.parameters())
+
+
+def test_sharded_evaluator_micro_batches():
+    from vcnf_amd.sharded import ShardedEvaluator
+    calls = []
+
+    def fake_log_prob(x, ctx=None):
+        calls.append(len(x))
+        return x.sum(1) + (0 if ctx is None else ctx.sum(1))
+    x, c = torch.randn(1000, 3), torch.randn(1000, 2)
+    ev = ShardedEvaluator(fake_log_prob, micro_batch=256)
+    got = ev.log_prob_shard(x, c)
+    assert calls == [256, 256, 256, 232]
+    assert torch.equal(got, x.sum(1) + c.sum(1))
+    assert abs(float(ev.mean_log_prob(x)) - float(x.sum(1).double().mean())) < 1e-9

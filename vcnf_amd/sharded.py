@@ -23,10 +23,15 @@ class ShardedEvaluator:
     all-reduce.  ``log_prob_fn(x[, context]) -> [b]`` is normally
     ``NormalizingFlow.log_prob`` on this rank's GPU."""
 
-    def __init__(self, log_prob_fn, sample_fn=None, group=None):
+    def __init__(self, log_prob_fn, sample_fn=None, group=None, micro_batch=None):
+        """``micro_batch``: evaluate the shard in chunks of at most this many samples.  Layers on
+        the three-step path materialise the conditioner output [b, d_t * (3K-1)] (config C5:
+        96 KB per sample and layer), so a 512K-sample shard is walked in bounded pieces; the
+        per-sample results are written into one preallocated [b] buffer."""
         self.log_prob_fn = log_prob_fn
         self.sample_fn = sample_fn
         self.group = group
+        self.micro_batch = micro_batch
 
     def _world(self):
         if dist.is_available() and dist.is_initialized():
@@ -37,10 +42,21 @@ class ShardedEvaluator:
         w, r = self._world()
         return shard_bounds(total, w, r)
 
+    def _call(self, x, context):
+        return self.log_prob_fn(x) if context is None else self.log_prob_fn(x, context)
+
     def log_prob_shard(self, x_shard, context_shard=None):
-        if context_shard is None:
-            return self.log_prob_fn(x_shard)
-        return self.log_prob_fn(x_shard, context_shard)
+        n = len(x_shard)
+        mb = self.micro_batch
+        if not mb or n <= mb:
+            return self._call(x_shard, context_shard)
+        out = None
+        for lo in range(0, n, mb):
+            part = self._call(x_shard[lo:lo + mb], None if context_shard is None else context_shard[lo:lo + mb])
+            if out is None:
+                out = torch.empty(n, dtype=part.dtype, device=part.device)
+            out[lo:lo + mb] = part
+        return out
 
     def reduce_stats(self, log_q):
         """[sum, count] over all ranks as fp64, one fused all-reduce."""
