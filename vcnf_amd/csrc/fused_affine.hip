@@ -71,24 +71,35 @@ __global__ __launch_bounds__(kFABlock) void fused_affine_layer_kernel(const Fuse
   const int m16 = lane & 15;
   const int q = lane >> 4;
   const int D = a.D;
-  const int XS = D + 1;                                   // odd-ish row stride: rows of a wave spread over banks
-  float* xs = smem + wave * 16 * XS;                      // this wave's 16 rows
   const __amdgpu_buffer_rsrc_t wr =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpack), 0, a.wpack_bytes, 0x00020000);
   const int voff = lane * 16;
   const int qoff = q * 16;
   const bool scaled = a.scale_map != VCNF_SCALE_NONE;
 
-  const long long ntiles = (a.B + 63) / 64;
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long b0 = tile * 64 + wave * 16;
-    const int rows = (int)max(0LL, min(16LL, a.B - b0));
-    __syncthreads();
-    for (int e = lane; e < 16 * D; e += 64) {
-      const int r = e / D, c = e - r * D;
-      xs[r * XS + c] = r < rows ? a.x[(b0 + r) * D + c] : 0.f;
+  // Waves are independent: each walks its own sequence of 16-sample tiles and stages them in its
+  // private LDS strip, so there is no workgroup barrier anywhere in the kernel (LDS operations
+  // of one wave execute in order; the staging writes are complete before the strip is read).
+  // The strip is a plain copy of the 16 contiguous rows (stride D): no index arithmetic on the
+  // way in or out, 16-byte transfers when D is a multiple of 4.
+  const int XS = D;
+  float* xs = smem + wave * 16 * XS;
+  const long long nwt = (a.B + 15) / 16;                       // wave tiles
+  const long long wstride = (long long)gridDim.x * (kFABlock / 64);
+  const int n16 = 16 * D;
+  for (long long wt = (long long)blockIdx.x * (kFABlock / 64) + wave; wt < nwt; wt += wstride) {
+    const long long b0 = wt * 16;
+    const int rows = (int)min(16LL, a.B - b0);
+    const int nvalid = rows * D;
+    const float* src = a.x + b0 * D;
+    if ((D & 3) == 0) {
+      for (int e = 4 * lane; e < n16; e += 256) {
+        const float4 v = e < nvalid ? *reinterpret_cast<const float4*>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(xs + e) = v;
+      }
+    } else {
+      for (int e = lane; e < n16; e += 64) xs[e] = e < nvalid ? src[e] : 0.f;
     }
-    __syncthreads();
 
     // ---- layer 1: natural k order, k-step s of lane group q reads input 4 s + q
     floatx4 h1[HB];
@@ -167,17 +178,18 @@ __global__ __launch_bounds__(kFABlock) void fused_affine_layer_kernel(const Fuse
         a.logdet[b0 + m16] = a.ld_mode ? a.logdet[b0 + m16] + o : o;
       }
     }
-    __syncthreads();
-    for (int e = lane; e < rows * D; e += 64) {
-      const int r = e / D, c = e - r * D;
-      a.y[(b0 + r) * D + c] = xs[r * XS + c];
+    float* dst = a.y + b0 * D;
+    if ((D & 3) == 0) {
+      for (int e = 4 * lane; e < nvalid; e += 256) *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(xs + e);
+    } else {
+      for (int e = lane; e < nvalid; e += 64) dst[e] = xs[e];
     }
   }
 }
 
 template <int KIG, int HB, int OBM>
 static int launch_fa(const FusedAffineArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)4 * 16 * (a.D + 1) * sizeof(float);
+  const size_t lds = (size_t)4 * 16 * a.D * sizeof(float);
   if (lds > 64 * 1024) return VCNF_ERR_SHAPE;
   const long long ntiles = (a.B + 63) / 64;
   const long long cap = 256 * 8;
