@@ -98,13 +98,16 @@ int vcnf_rqs_elementwise_strided_f32(const float* x, const float* uw, const floa
  * nets/mlp.py:30-58 for that case.  The conditioner reads x[:, cond_off : cond_off + c_in], the
  * features [t_off, t_off + d_t) are transformed, the rest is copied.  hidden in {32, 64, 128},
  * c_in <= 64, n_out <= 128.  wpack: vcnf_affine_layer_fused_pack_floats(...) floats in the
- * fragment order documented in vcnf_amd/fused_affine.py. */
+ * fragment order documented in vcnf_amd/fused_affine.py.  in_gather / out_gather (int32[features],
+ * may be NULL) fold a neighbouring Permute (flows/mixing.py:32-54) into the layer: the block is
+ * applied to x[:, in_gather] and the result returned as result[:, out_gather]. */
 int vcnf_affine_layer_fused_supported(int32_t c_in, int32_t hidden, int32_t n_out, int32_t features);
 int64_t vcnf_affine_layer_fused_pack_floats(int32_t c_in, int32_t hidden, int32_t n_out);
 int vcnf_affine_layer_fused_f32(const float* x, float* y, float* logdet, int64_t batch, int32_t features,
                                 int32_t cond_off, int32_t c_in, int32_t t_off, int32_t d_t,
                                 int32_t hidden, float leaky_slope, int scale_map,
                                 const float* wpack, int64_t wpack_floats,
+                                const int32_t* in_gather, const int32_t* out_gather,
                                 int inverse, int ld_mode, float ld_sign, void* stream);
 
 /* Vector-Jacobian product of vcnf_rqs_elementwise_f32 (training path; the reference

@@ -923,3 +923,32 @@ def test_fused_rqs_layer_d32_family(hip, ctx_dim, precision):
             parity(ld, w32[1], w64[1], rtol=1e-5, atol=2e-5, what="fused ld " + dirn)
             parity(z2, w32[0], w64[0], what="split z " + dirn)
     nf.check_discriminant()
+
+
+def test_permute_folded_into_fused_affine_layer(hip):
+    """NormalizingFlow folds a Permute next to a one-kernel affine layer into that kernel's load /
+    store index; result identical to running the two layers separately (shuffle and swap)."""
+    torch.manual_seed(8)
+    d = 12
+    for mode in ("shuffle", "swap"):
+        flows = []
+        for _ in range(3):
+            flows += [nf.flows.AffineCouplingBlock(nf.nets.MLP([6, 32, 32, 12])), nf.flows.Permute(d, mode=mode)]
+        with torch.no_grad():
+            for f in flows[::2]:
+                f.flows[1].param_map.net[4].weight.normal_(0, 0.2)
+        model = nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows).cuda()
+        x, eps = torch.randn(333, d, device="cuda"), torch.randn(333, d, device="cuda")
+        with torch.no_grad():
+            lp, (z, lq) = model.log_prob(x), model.sample_from(eps)
+            zz, lq2 = model.q0.from_noise(eps)                 # the same stack, layer by layer
+            for f in model.flows:
+                zz, ld = f(zz)
+                lq2 = lq2 - ld
+            yy, lp2 = x, torch.zeros(333, device="cuda")
+            for f in reversed(model.flows):
+                yy, ld = f.inverse(yy)
+                lp2 = lp2 + ld
+            lp2 = lp2 + model.q0.log_prob(yy)
+        assert torch.allclose(z, zz, rtol=1e-6, atol=1e-6) and torch.allclose(lq, lq2, rtol=1e-6, atol=1e-5)
+        assert torch.allclose(lp, lp2, rtol=1e-6, atol=1e-5)

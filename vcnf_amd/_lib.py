@@ -43,7 +43,7 @@ PROTOTYPES = {
     "vcnf_affine_layer_fused_supported": ([_I32, _I32, _I32, _I32], _INT),
     "vcnf_affine_layer_fused_pack_floats": ([_I32, _I32, _I32], _I64),
     "vcnf_affine_layer_fused_f32": ([_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _INT, _P, _I64,
-                                     _INT, _INT, _F32, _P], _INT),
+                                     _P, _P, _INT, _INT, _F32, _P], _INT),
     "vcnf_rqs_packed_bwd_f32": ([_P, _P, _I64, _I64, _P, _P, _P, _P, _I64, ctypes.POINTER(RqsCfg), _INT, _P], _INT),
     "vcnf_rqs_shared_bwd_groups": ([_I64, _I64], _I64),
     "vcnf_rqs_shared_bwd_f32": ([_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _I64,
@@ -428,7 +428,7 @@ def affine_coupling(z, param, t_off, d_t, scale_map, inverse, logdet=None, sign=
 
 
 def affine_layer_fused(z, wpack, cond_off, c_in, t_off, d_t, hidden, slope, scale_map, inverse, logdet=None,
-                       sign=1.0):
+                       sign=1.0, in_gather=None, out_gather=None):
     """Whole AffineCouplingBlock (MLP conditioner included) in one kernel; csrc/fused_affine.hip."""
     dev = require_device(z, wpack, logdet)
     z = z.contiguous()
@@ -442,6 +442,7 @@ def affine_layer_fused(z, wpack, cond_off, c_in, t_off, d_t, hidden, slope, scal
         st = lib().vcnf_affine_layer_fused_f32(_ptr(z), _ptr(out), _ptr(logdet) if scale_map != SCALE_NONE else None,
                                                b, d, int(cond_off), int(c_in), int(t_off), int(d_t), int(hidden),
                                                float(slope), int(scale_map), _ptr(wpack), wpack.numel(),
+                                               _ptr(in_gather), _ptr(out_gather),
                                                int(bool(inverse)), mode, float(sign), _stream())
     _check(st, "vcnf_affine_layer_fused_f32")
     return out, logdet

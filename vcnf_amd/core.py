@@ -16,6 +16,9 @@ the AttributeError the reference has at this HEAD.
 import torch
 from torch import nn
 
+from .flows.affine.coupling import AffineCouplingBlock
+from .flows.mixing import Permute
+
 
 class NormalizingFlow(nn.Module):
     def __init__(self, q0, flows, p=None, categoricals=None, catlevels=None, catvdeqs=None):
@@ -33,8 +36,19 @@ class NormalizingFlow(nn.Module):
         log-density at the end (core.py:176-183)."""
         log_q = torch.zeros(len(x), dtype=x.dtype, device=x.device)
         z = x
-        for flow in reversed(self.flows):
+        order = list(reversed(self.flows))
+        skip = False
+        for i, flow in enumerate(order):
+            if skip:
+                skip = False
+                continue
             ctx = {'context': context} if (context is not None and getattr(flow, 'takes_context', False)) else {}
+            # a Permute undone right before a one-kernel affine layer becomes that kernel's load index
+            if (isinstance(flow, Permute) and i + 1 < len(order) and z.dim() == 2
+                    and isinstance(order[i + 1], AffineCouplingBlock) and order[i + 1].fusable(z)):
+                z = order[i + 1].run_with_permute(z, True, log_q, 1.0, in_gather=flow._idx32(True, z.device))
+                skip = True
+                continue
             if hasattr(flow, 'inverse_into'):
                 z = flow.inverse_into(z, log_q, **ctx)
             else:
@@ -58,8 +72,19 @@ class NormalizingFlow(nn.Module):
         return self._push(z, log_q, context)
 
     def _push(self, z, log_q, context):
-        for flow in self.flows:
+        order = list(self.flows)
+        skip = False
+        for i, flow in enumerate(order):
+            if skip:
+                skip = False
+                continue
             ctx = {'context': context} if (context is not None and getattr(flow, 'takes_context', False)) else {}
+            # a Permute applied right after a one-kernel affine layer becomes that kernel's store index
+            if (isinstance(flow, AffineCouplingBlock) and i + 1 < len(order) and isinstance(order[i + 1], Permute)
+                    and z.dim() == 2 and flow.fusable(z)):
+                z = flow.run_with_permute(z, False, log_q, -1.0, out_gather=order[i + 1]._idx32(False, z.device))
+                skip = True
+                continue
             if hasattr(flow, 'forward_into'):
                 z = flow.forward_into(z, log_q, **ctx)
             else:

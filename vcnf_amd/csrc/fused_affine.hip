@@ -38,6 +38,8 @@ struct FusedAffineArgs {
   int OB;            // output row blocks = ceil(n_out / 16)
   int scale_map, inverse, ld_mode;
   float ld_sign, slope;
+  const int32_t* in_gather;    // optional: the layer sees x[:, in_gather]   (a Permute before the block)
+  const int32_t* out_gather;   // optional: the result is y[:, out_gather]   (a Permute after the block)
   int off_b1, off_w2, off_b2, off_w3, off_b3;   // float offsets inside wpack (w1 at 0)
 };
 
@@ -92,7 +94,12 @@ __global__ __launch_bounds__(kFABlock) void fused_affine_layer_kernel(const Fuse
     const int rows = (int)min(16LL, a.B - b0);
     const int nvalid = rows * D;
     const float* src = a.x + b0 * D;
-    if ((D & 3) == 0) {
+    if (a.in_gather) {
+      for (int e = lane; e < n16; e += 64) {
+        const int r = e / D, c = e - r * D;
+        xs[e] = e < nvalid ? src[r * D + a.in_gather[c]] : 0.f;
+      }
+    } else if ((D & 3) == 0) {
       for (int e = 4 * lane; e < n16; e += 256) {
         const float4 v = e < nvalid ? *reinterpret_cast<const float4*>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(xs + e) = v;
@@ -179,7 +186,12 @@ __global__ __launch_bounds__(kFABlock) void fused_affine_layer_kernel(const Fuse
       }
     }
     float* dst = a.y + b0 * D;
-    if ((D & 3) == 0) {
+    if (a.out_gather) {
+      for (int e = lane; e < nvalid; e += 64) {
+        const int r = e / D, c = e - r * D;
+        dst[e] = xs[r * D + a.out_gather[c]];
+      }
+    } else if ((D & 3) == 0) {
       for (int e = 4 * lane; e < nvalid; e += 256) *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(xs + e);
     } else {
       for (int e = lane; e < nvalid; e += 64) dst[e] = xs[e];
@@ -223,6 +235,7 @@ extern "C" int vcnf_affine_layer_fused_f32(const float* x, float* y, float* logd
                                            int32_t cond_off, int32_t c_in, int32_t t_off, int32_t d_t,
                                            int32_t hidden, float leaky_slope, int scale_map,
                                            const float* wpack, int64_t wpack_floats,
+                                           const int32_t* in_gather, const int32_t* out_gather,
                                            int inverse, int ld_mode, float ld_sign, void* stream) {
   const int n_out = scale_map == VCNF_SCALE_NONE ? d_t : 2 * d_t;
   if (batch < 0 || !fa_shape_ok(c_in, hidden, n_out, features)) return VCNF_ERR_SHAPE;
@@ -237,6 +250,7 @@ extern "C" int vcnf_affine_layer_fused_f32(const float* x, float* y, float* logd
   a.B = batch; a.D = features; a.c_in = c_in; a.cond_off = cond_off; a.d_t = d_t; a.t_off = t_off;
   a.KI = (c_in + 3) / 4; a.OB = (n_out + 15) / 16;
   a.scale_map = scale_map; a.inverse = inverse ? 1 : 0; a.ld_mode = ld_mode; a.ld_sign = ld_sign; a.slope = leaky_slope;
+  a.in_gather = in_gather; a.out_gather = out_gather;
   const int KIG = c_in <= 16 ? 1 : 4, HB = hidden / 16;
   a.off_b1 = HB * KIG * 256;
   a.off_w2 = a.off_b1 + 16 * HB;

@@ -142,6 +142,18 @@ class AffineCouplingBlock(Flow):
         # inputs (fused_affine.eligible); False forces the three-step path
         self.fused = True
 
+    def fusable(self, z):
+        """True when this call would take the one-kernel path (which can also absorb a Permute)."""
+        core = self.flows[1]
+        return (self.fused and not autograd.needs_grad(z, *core.param_map.parameters())
+                and fused_affine.eligible(self, z))
+
+    def run_with_permute(self, z, inverse, log_q, sign, in_gather=None, out_gather=None):
+        """One-kernel layer with a neighbouring Permute folded into its load / store indexing."""
+        core = self.flows[1]
+        return fused_affine.run(self, z, _scale_code(core.scale, core.scale_map), inverse, log_q, sign,
+                                in_gather, out_gather)[0]
+
     def _run(self, z, inverse, log_q=None, sign=1.0):
         if self.split_mode not in ('channel', 'channel_inv'):
             # checkerboard: explicit Split -> AffineCoupling (pair form of the kernel) -> Merge

@@ -102,7 +102,7 @@ def packed_weights(block):
     return cache['buf'], (l1, l2, l3), slope
 
 
-def run(block, z, code, inverse, log_q=None, sign=1.0):
+def run(block, z, code, inverse, log_q=None, sign=1.0, in_gather=None, out_gather=None):
     """Whole AffineCouplingBlock on [B, D] in one launch; same (out, log_det) contract as the
     three-step path of AffineCouplingBlock._run."""
     buf, (l1, _, l3), slope = packed_weights(block)
@@ -113,4 +113,4 @@ def run(block, z, code, inverse, log_q=None, sign=1.0):
     else:
         cond_off, t_off, d_t = head, 0, head
     return _lib.affine_layer_fused(z, buf, cond_off, l1.in_features, t_off, d_t, l1.out_features, slope, code,
-                                   inverse, logdet=log_q, sign=sign)
+                                   inverse, logdet=log_q, sign=sign, in_gather=in_gather, out_gather=out_gather)
