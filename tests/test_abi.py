@@ -75,3 +75,43 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib._build, "LIB", str(tmp_path / "nope.so"))
     with pytest.raises(vcnf_amd.VcnfError):
         _lib.lib()
+
+
+def test_validation_status_codes_of_the_later_entry_points():
+    """Entry points added after the first slice: shape / enum / NULL validation happens on the host
+    before anything is launched."""
+    L = vcnf_amd.lib()
+    cfg = _lib.make_cfg(8, "linear", tail_bound=3.0)
+    circ = _lib.make_cfg(8, "circular", tail_bound=3.0)
+    assert circ.tails == _lib.TAILS_CIRCULAR and _lib.n_derivatives(circ) == 8
+    fake = ctypes.c_void_p(0x1000)
+    # strided spline: inner / k_stride must be >= 1
+    assert L.vcnf_rqs_elementwise_strided_f32(fake, fake, fake, fake, 8, 8, 7, 0, 1, 0, fake, fake, 4,
+                                              ctypes.byref(cfg), 0, None, None) == 2
+    assert L.vcnf_rqs_elementwise_strided_f32(fake, fake, fake, fake, 8, 8, 7, 1, 1, 0, fake, fake, 0,
+                                              ctypes.byref(cfg), 0, None, None) == 0      # empty batch
+    # packed VJP: NULL gradient buffer
+    assert L.vcnf_rqs_packed_bwd_f32(fake, fake, 1, 32, fake, fake, None, fake, 4, ctypes.byref(cfg), 0, None) == 1
+    # shared-logit VJP: groups must be what vcnf_rqs_shared_bwd_groups says, bins in {4, 8, 10, 16}
+    g = L.vcnf_rqs_shared_bwd_groups(1000, 32)
+    assert g == 1000 and L.vcnf_rqs_shared_bwd_groups(1 << 20, 32) == 8192
+    assert L.vcnf_rqs_shared_bwd_f32(fake, fake, fake, fake, 1000, 32, 32, fake, fake, fake, fake, g + 1,
+                                     ctypes.byref(cfg), 0, None) == 2
+    # fused layer shape families
+    assert L.vcnf_rqs_layer_fused_supported(32, 32, 16, 128, 2, 8, _lib.TAILS_LINEAR) == 1
+    assert L.vcnf_rqs_layer_fused_supported(16, 16, 0, 128, 2, 8, _lib.TAILS_LINEAR) == 1
+    assert L.vcnf_rqs_layer_fused_supported(32, 32, 16, 128, 2, 8, _lib.TAILS_CIRCULAR) == 0
+    assert L.vcnf_rqs_layer_fused_supported(24, 24, 0, 128, 2, 8, _lib.TAILS_LINEAR) == 0
+    assert L.vcnf_rqs_layer_fused_pack_floats(24, 24, 0) == 0
+    assert L.vcnf_affine_layer_fused_supported(16, 64, 32, 32) == 1
+    assert L.vcnf_affine_layer_fused_supported(16, 48, 32, 32) == 0          # hidden not in {32, 64, 128}
+    assert L.vcnf_affine_layer_fused_supported(65, 64, 32, 130) == 0         # conditioner input too wide
+    n = L.vcnf_affine_layer_fused_pack_floats(16, 64, 32)
+    assert n == 4 * 1 * 256 + 64 + 4 * 4 * 256 + 64 + 2 * 4 * 256 + 32
+    # wrong packed size / transformed range outside the row / unknown scale map
+    assert L.vcnf_affine_layer_fused_f32(fake, fake, fake, 4, 32, 0, 16, 16, 16, 64, 0.0, 0, fake, n - 1,
+                                         None, None, 0, 0, 1.0, None) == 2
+    assert L.vcnf_affine_layer_fused_f32(fake, fake, fake, 4, 32, 0, 16, 20, 16, 64, 0.0, 0, fake, n,
+                                         None, None, 0, 0, 1.0, None) == 2
+    assert L.vcnf_affine_layer_fused_f32(fake, fake, fake, 4, 32, 0, 16, 16, 16, 64, 0.0, 9, fake, n,
+                                         None, None, 0, 0, 1.0, None) in (2, 5)
