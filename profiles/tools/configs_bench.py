@@ -2,7 +2,7 @@
 import sys, time
 import os
 _R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path[:0] = [_R, _R + '/tests', _R + '/tests/golden']
+sys.path[:0] = [_R]
 import torch
 import vcnf_amd as nf
 torch.manual_seed(0)
@@ -18,6 +18,22 @@ def affine(layers, d, widths):
     for _ in range(layers):
         flows += [nf.flows.AffineCouplingBlock(nf.nets.MLP(widths)), nf.flows.Permute(d, mode="swap")]
     return nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows).cuda()
+
+def _glow_model(levels, blocks, hidden, input_shape):
+    q0, merges, flows, L = [], [], [], levels
+    for i in range(L):
+        fl = [nf.flows.GlowBlock(input_shape[0] * 2 ** (L + 1 - i), hidden, split_mode="channel", scale=True)
+              for _ in range(blocks)]
+        fl += [nf.flows.Squeeze()]
+        flows += [fl]
+        if i > 0:
+            merges += [nf.flows.Merge()]
+            shape = (input_shape[0] * 2 ** (L - i), input_shape[1] // 2 ** (L - i), input_shape[2] // 2 ** (L - i))
+        else:
+            shape = (input_shape[0] * 2 ** (L + 1), input_shape[1] // 2 ** L, input_shape[2] // 2 ** L)
+        q0 += [nf.distributions.DiagGaussian(shape)]
+    return nf.MultiscaleFlow(q0, flows, merges, class_cond=False)
+
 
 def report(name, B, dt, note=""):
     print("%-3s batch %8d: %9.2f ms/step  %10.2f M transforms/s  %s" % (name, B, dt * 1e3, 2 * B / dt / 1e6, note), flush=True)
@@ -40,7 +56,6 @@ with torch.no_grad():
     report("C3", B, timeit(lambda: (m.log_prob(x, c), m.sample_from(e, c)), 5))
     del m, x, c, e
     # C4: 32x32x3 multiscale Glow (3 levels x 4 blocks, 64 hidden channels), per-GPU share 16384 of 131072
-    from test_gpu_parity import _glow_model
     m = _glow_model(levels=3, blocks=4, hidden=64, input_shape=(3, 32, 32)).cuda(); B = 2048
     x = torch.randn(B, 3, 32, 32, device='cuda')
     m.log_prob(x)            # ActNorm data-dependent init
