@@ -18,39 +18,42 @@ class Flow(nn.Module):
 
 
 class Reverse(Flow):
-    """Swaps forward and inverse of the wrapped flow (base.py:24-40)."""
+    """The wrapped flow with its two directions exchanged (base.py:24-40); the wrapped module
+    keeps the attribute name ``flow`` (state-dict prefix)."""
 
     def __init__(self, flow):
         super().__init__()
-        self.flow = flow
+        self.add_module('flow', flow)
 
     def forward(self, z):
-        return self.flow.inverse(z)
+        inner = self.flow
+        return inner.inverse(z)
 
     def inverse(self, z):
-        return self.flow.forward(z)
+        inner = self.flow
+        return inner.forward(z)
 
 
 class Composite(Flow):
-    """Chains flows in the given order (base.py:43-70).  The running log-det
-    starts on the input's device and dtype; the reference allocates it on the
-    CPU (base.py:59), which fails for GPU inputs - deliberate deviation."""
+    """Flows applied one after the other, log-dets summed (base.py:43-70); sub-modules live in
+    ``_flows`` (state-dict prefix).  The running log-det starts on the input's device and dtype;
+    the reference allocates it on the CPU (base.py:59), which fails for GPU inputs - deliberate
+    deviation."""
 
     def __init__(self, flows):
         super().__init__()
-        self._flows = nn.ModuleList(flows)
+        self._flows = nn.ModuleList(list(flows))
 
-    @staticmethod
-    def _chain(inputs, steps):
-        total = torch.zeros(inputs.shape[0], dtype=inputs.dtype, device=inputs.device)
-        out = inputs
-        for step in steps:
-            out, ld = step(out)
-            total += ld
-        return out, total
+    def _run(self, z, backwards):
+        log_det = z.new_zeros(z.shape[0])
+        members = list(self._flows)
+        for member in (reversed(members) if backwards else members):
+            z, ld = (member.inverse(z) if backwards else member(z))
+            log_det = log_det + ld
+        return z, log_det
 
     def forward(self, inputs):
-        return self._chain(inputs, self._flows)
+        return self._run(inputs, False)
 
     def inverse(self, inputs):
-        return self._chain(inputs, [f.inverse for f in reversed(self._flows)])
+        return self._run(inputs, True)
