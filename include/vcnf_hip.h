@@ -110,6 +110,14 @@ int vcnf_affine_layer_fused_f32(const float* x, float* y, float* logdet, int64_t
                                 const int32_t* in_gather, const int32_t* out_gather,
                                 int inverse, int ld_mode, float ld_sign, void* stream);
 
+/* Per-position splines whose logits are shared by the whole batch (coupling.py:211-240): x [n] with
+ * position i % period, logits sw, sh [period, K], sd [period, K-1 | K | K+1].  `tables` is a caller
+ * workspace of period * 3 * (K + 1) floats: the knots of every position are generated once into it,
+ * the elements then search their row (no softmax per element). */
+int vcnf_rqs_shared_f32(const float* x, const float* sw, const float* sh, const float* sd, int64_t period,
+                        float* tables, float* y, float* logabsdet, int64_t n,
+                        const vcnf_rqs_cfg* cfg, int inverse, int32_t* bad_discriminant, void* stream);
+
 /* Vector-Jacobian product of vcnf_rqs_elementwise_f32 (training path; the reference
  * obtains it from autograd over utils/splines.py:88-193).  Inputs as the forward call
  * plus the upstream gradients g_y[n], g_logabsdet[n]; outputs g_x[n] and dense
@@ -139,6 +147,21 @@ int vcnf_rqs_shared_bwd_f32(const float* x, const float* sw, const float* sh, co
                             const float* g_y, const float* g_logabsdet,
                             float* g_x, float* partial, int64_t groups,
                             const vcnf_rqs_cfg* cfg, int inverse, void* stream);
+
+/* Last conditioner layer + splines of an RQS coupling for any number of transformed features:
+ * h [B, hidden] is the conditioner trunk's output (input of nets/resnet.py:105 final_layer), wpack the
+ * final layer's weights and bias in matrix-core fragment order (vcnf_amd/fused_final.py).  Writes the
+ * transformed columns y[:, transform_idx] (the caller has filled the identity columns) and the
+ * per-group-block log|det| rows partial[vcnf_rqs_final_fused_partial_rows(d_t, K), B] whose sum over
+ * rows is the transform half's log|det|.  Replaces nets/resnet.py:105, coupling.py:147-159 and
+ * :309-343 without materialising the [B, d_t * (3K-1)] logits.  hidden = 128, linear tails, K in {8, 16}. */
+int vcnf_rqs_final_fused_supported(int32_t d_t, int32_t hidden, int32_t num_bins, int32_t tails);
+int64_t vcnf_rqs_final_fused_pack_floats(int32_t d_t, int32_t hidden, int32_t num_bins);
+int64_t vcnf_rqs_final_fused_partial_rows(int32_t d_t, int32_t num_bins);
+int vcnf_rqs_final_fused_f32(const float* x, const float* h, float* y, float* partial,
+                             int64_t batch, int32_t features, const int32_t* transform_idx, int32_t d_t,
+                             int32_t hidden, const float* wpack, int64_t wpack_floats,
+                             const vcnf_rqs_cfg* cfg, int inverse, int32_t* bad_discriminant, void* stream);
 
 /* One RQS coupling layer on x[B,D] -> y[B,D].
  * Replaces Coupling.forward / .inverse (flows/neural_spline/coupling.py:70-96 /

@@ -952,3 +952,47 @@ def test_permute_folded_into_fused_affine_layer(hip):
             lp2 = lp2 + model.q0.log_prob(yy)
         assert torch.allclose(z, zz, rtol=1e-6, atol=1e-6) and torch.allclose(lq, lq2, rtol=1e-6, atol=1e-5)
         assert torch.allclose(lp, lp2, rtol=1e-6, atol=1e-5)
+
+
+# ---------------------------------------------------------------- last layer + splines in one kernel (any d_t)
+@pytest.mark.parametrize("d,k,blocks,ctx_dim,batch", [
+    (64, 8, 3, 16, 1000),        # C3-like but 3 residual blocks: outside the one-kernel families
+    (1024, 16, 2, 0, 300),       # config C5's layer shape
+    (42, 8, 1, 0, 77),           # d_t = 21: last feature group partly empty
+    (10, 16, 2, 5, 4097)])
+def test_final_layer_fused_with_splines(hip, d, k, blocks, ctx_dim, batch):
+    """Conditioner trunk on PyTorch-ROCm, last Linear + splines in csrc/fused_final.hip (fp16 split-half
+    matrix path, logits never materialised) against the three-step path and the oracle."""
+    from vcnf_amd import fused, fused_final
+    torch.manual_seed(d + k)
+    lay = nf.flows.CoupledRationalQuadraticSpline(d, blocks, 128, k, reverse_mask=bool(d % 3),
+                                                  num_context_channels=ctx_dim or None)
+    with torch.no_grad():
+        for n, p in lay.named_parameters():
+            if "final_layer" in n or "unconditional" in n:
+                p.normal_(0, 0.4)
+    sd = {n: v.detach().clone() for n, v in lay.state_dict().items()}
+    lay = lay.cuda()
+    x = 1.5 * torch.randn(batch, d)
+    ctx = torch.randn(batch, ctx_dim) if ctx_dim else None
+    cg = dev(ctx) if ctx_dim else None
+    assert not fused.eligible(lay.prqct, cg) and fused_final.eligible(lay.prqct, dev(x), cg)
+    o32 = oracle_rqs_coupling(sd, "prqct.", k, 3.0, 128)
+    o64 = oracle_rqs_coupling({n: (v.double() if v.is_floating_point() else v) for n, v in sd.items()}, "prqct.", k, 3.0, 128)
+    with torch.no_grad():
+        for dirn in ("forward", "inverse"):
+            lay.prqct.fused = True
+            z, ld = getattr(lay, dirn)(dev(x), cg)
+            lay.prqct.fused = False
+            z2, ld2 = getattr(lay, dirn)(dev(x), cg)
+            w32 = getattr(o32, dirn)(x, ctx)
+            w64 = getattr(o64, dirn)(x.double(), ctx.double() if ctx_dim else None)
+            parity(z, w32[0], w64[0], what="final-fused z " + dirn)
+            parity(ld, w32[1], w64[1], rtol=1e-5, atol=2e-5 * max(1, d // 64), what="final-fused ld " + dirn)
+            parity(z2, w32[0], w64[0], what="three-step z " + dirn)
+        lay.prqct.fused = True
+        lq = torch.full((batch,), 0.5, device="cuda")
+        z3 = lay.inverse_into(dev(x), lq, **({"context": cg} if ctx_dim else {}))
+        zi, ldi = lay.inverse(dev(x), cg)
+        assert torch.equal(z3, zi) and torch.allclose(lq, 0.5 + ldi, rtol=1e-6, atol=1e-5)
+    nf.check_discriminant()

@@ -44,6 +44,12 @@ PROTOTYPES = {
     "vcnf_affine_layer_fused_pack_floats": ([_I32, _I32, _I32], _I64),
     "vcnf_affine_layer_fused_f32": ([_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _INT, _P, _I64,
                                      _P, _P, _INT, _INT, _F32, _P], _INT),
+    "vcnf_rqs_shared_f32": ([_P, _P, _P, _P, _I64, _P, _P, _P, _I64, ctypes.POINTER(RqsCfg), _INT, _P, _P], _INT),
+    "vcnf_rqs_final_fused_supported": ([_I32, _I32, _I32, _I32], _INT),
+    "vcnf_rqs_final_fused_pack_floats": ([_I32, _I32, _I32], _I64),
+    "vcnf_rqs_final_fused_partial_rows": ([_I32, _I32], _I64),
+    "vcnf_rqs_final_fused_f32": ([_P, _P, _P, _P, _I64, _I32, _P, _I32, _I32, _P, _I64, ctypes.POINTER(RqsCfg), _INT,
+                                  _P, _P], _INT),
     "vcnf_rqs_packed_bwd_f32": ([_P, _P, _I64, _I64, _P, _P, _P, _P, _I64, ctypes.POINTER(RqsCfg), _INT, _P], _INT),
     "vcnf_rqs_shared_bwd_groups": ([_I64, _I64], _I64),
     "vcnf_rqs_shared_bwd_f32": ([_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _I64,
@@ -256,12 +262,12 @@ def rqs_elementwise_shared(x, uw, uh, ud, cfg, inverse, allow_grad=False):
     uw, uh, ud = uw.contiguous(), uh.contiguous(), ud.contiguous()
     y, lad = torch.empty_like(x), torch.empty_like(x)
     period = int(x[0].numel())
+    tables = torch.empty(period * 3 * (k + 1), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        st = lib().vcnf_rqs_elementwise_strided_f32(
-            _ptr(x), _ptr(uw), _ptr(uh), _ptr(ud), k, k, nd, 1, 1, period, _ptr(y), _ptr(lad), x.numel(),
-            ctypes.byref(cfg), int(bool(inverse)),
-            _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
-    _check(st, "vcnf_rqs_elementwise_strided_f32")
+        st = lib().vcnf_rqs_shared_f32(_ptr(x), _ptr(uw), _ptr(uh), _ptr(ud), period, _ptr(tables), _ptr(y), _ptr(lad),
+                                       x.numel(), ctypes.byref(cfg), int(bool(inverse)),
+                                       _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
+    _check(st, "vcnf_rqs_shared_f32")
     return y, lad
 
 
@@ -425,6 +431,25 @@ def affine_coupling(z, param, t_off, d_t, scale_map, inverse, logdet=None, sign=
                                             mode, float(sign), _stream())
     _check(st, "vcnf_affine_coupling_f32")
     return out, logdet
+
+
+def rqs_final_fused(x, h, out, tf_idx, d_t, hidden, wpack, cfg, inverse):
+    """Last conditioner layer + splines (csrc/fused_final.hip): writes out[:, tf_idx], returns the partial
+    log-det rows [rows, B]."""
+    dev = require_device(x, h, out, wpack)
+    x, h = x.contiguous(), h.contiguous()
+    if not out.is_contiguous():
+        raise VcnfError("rqs_final_fused writes into a contiguous output tensor")
+    b, d = x.shape
+    rows = int(lib().vcnf_rqs_final_fused_partial_rows(d_t, cfg.num_bins))
+    partial = torch.empty(rows, b, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = lib().vcnf_rqs_final_fused_f32(_ptr(x), _ptr(h), _ptr(out), _ptr(partial), b, d, _ptr(tf_idx), int(d_t),
+                                            int(hidden), _ptr(wpack), wpack.numel(), ctypes.byref(cfg),
+                                            int(bool(inverse)),
+                                            _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
+    _check(st, "vcnf_rqs_final_fused_f32")
+    return partial
 
 
 def affine_layer_fused(z, wpack, cond_off, c_in, t_off, d_t, hidden, slope, scale_map, inverse, logdet=None,

@@ -8,7 +8,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libvcnf_hip.so")
-SOURCES = ["rqs_kernels.hip", "affine_kernels.hip", "fused_layer.hip", "fused_layer_v2.hip", "fused_layer_v3.hip", "fused_layer_v4.hip", "fused_affine.hip", "rqs_backward.hip"]
+SOURCES = ["rqs_kernels.hip", "affine_kernels.hip", "fused_layer.hip", "fused_layer_v2.hip", "fused_layer_v3.hip", "fused_layer_v4.hip", "fused_affine.hip", "fused_final.hip", "rqs_backward.hip"]
 HEADERS = ["rqs_math.hpp", "fused_common.hpp", os.path.join("..", "..", "include", "vcnf_hip.h")]
 
 

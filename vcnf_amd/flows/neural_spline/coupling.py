@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from ..base import Flow
-from ... import _lib, fused, autograd
+from ... import _lib, fused, fused_final, autograd
 from ...utils import splines
 
 
@@ -279,6 +279,9 @@ class PiecewiseRationalQuadraticCoupling(Flow):
         if self.fused and fused.eligible(self, context):
             # conditioner + splines in one kernel (csrc/fused_layer.hip)
             return fused.run(self, inputs, context, sampling, log_q, sign)
+        if self.fused and fused_final.eligible(self, inputs, context):
+            # conditioner trunk on PyTorch-ROCm, last layer + splines in one kernel (csrc/fused_final.hip)
+            return fused_final.run(self, inputs, context, sampling, log_q, sign)
         params = self._params(inputs, context, sampling)
         expect = self.num_transform_features * self._transform_dim_multiplier()
         if params.dim() != 2 or params.shape[1] != expect:

@@ -1,0 +1,103 @@
+"""Host side of csrc/fused_final.hip: the last conditioner layer + splines of an RQS coupling in one
+kernel for any number of transformed features (hidden width 128, linear tails, 8 or 16 bins).
+
+Packed buffer (floats): for feature group g (features 4 g .. 4 g + 3), row block b, k-step s the two
+fragments hi | lo of 64 lanes x 8 halves, lane = 16 q' + i holding
+    W[(4 g + (i >> 2)) * P + 4 b + (i & 3)][32 s + 8 q' + j],  j = 0..7      (natural k order: the
+operand comes from memory, not from a previous layer's accumulators), rows with 4 b + (i & 3) >= P or
+feature >= d_t zero; then the bias rows [g][q][4 P4] in accumulator order.
+"""
+import torch
+
+from . import _lib
+from .fused import _split_halves, _as_floats
+
+
+def eligible(coupling, inputs, context):
+    from .nets.resnet import ResidualNet
+    net = coupling.transform_net
+    if type(net) is not ResidualNet or net.preprocessing is not None or inputs.dim() != 2:
+        return False
+    if any(b.use_batch_norm or (b.dropout.p > 0 and b.training) for b in net.blocks):
+        return False
+    if (context is None) != (not net.context_features):
+        return False
+    from . import fused
+    if fused.precision_of(coupling) != fused.PREC_F16X3:        # fused_precision='fp32' asks for exact fp32 products
+        return False
+    code = {'linear': _lib.TAILS_LINEAR, None: _lib.TAILS_NONE, 'circular': _lib.TAILS_CIRCULAR}.get(coupling.tails, -1)
+    return bool(_lib.lib().vcnf_rqs_final_fused_supported(coupling.num_transform_features, net.hidden_features,
+                                                          coupling.num_bins, code))
+
+
+def pack(weight, bias, d_t, k):
+    p = 3 * k - 1
+    p4 = (p + 3) // 4
+    ng = (d_t + 3) // 4
+    hdim = weight.shape[1]
+    dev = weight.device
+    g = torch.arange(ng, device=dev).view(-1, 1, 1, 1, 1)
+    b = torch.arange(p4, device=dev).view(1, -1, 1, 1, 1)
+    s = torch.arange(hdim // 32, device=dev).view(1, 1, -1, 1, 1)
+    lane = torch.arange(64, device=dev).view(1, 1, 1, -1, 1)
+    j = torch.arange(8, device=dev).view(1, 1, 1, 1, -1)
+    i = lane & 15
+    t = 4 * b + (i & 3)
+    feat = 4 * g + (i >> 2)
+    shape = (ng, p4, hdim // 32, 64, 8)
+    ok = ((t < p) & (feat < d_t)).expand(shape)
+    rows = torch.where((t < p) & (feat < d_t), feat * p + t, torch.zeros_like(feat + t)).expand(shape)
+    cols = (32 * s + 8 * (lane >> 4) + j).expand(shape)
+    w = torch.where(ok, weight[rows, cols], torch.zeros((), device=dev, dtype=weight.dtype))
+    hi, lo = _split_halves(w)                                   # [ng, p4, ns, 64, 8] each
+    frag = torch.stack([hi, lo], dim=3)                         # [ng, p4, ns, 2, 64, 8]
+    g2 = torch.arange(ng, device=dev).view(-1, 1, 1)
+    q2 = torch.arange(4, device=dev).view(1, -1, 1)
+    t2 = torch.arange(4 * p4, device=dev).view(1, 1, -1)
+    okb = ((t2 < p) & (4 * g2 + q2 < d_t)).expand(ng, 4, 4 * p4)
+    idx = torch.where(okb, ((4 * g2 + q2) * p + t2).expand(ng, 4, 4 * p4), torch.zeros((), device=dev, dtype=torch.long))
+    bf = torch.where(okb, bias[idx], torch.zeros((), device=dev, dtype=bias.dtype))
+    return torch.cat([_as_floats(frag), bf.reshape(-1).float()]).contiguous()
+
+
+def packed_weights(coupling):
+    lin = coupling.transform_net.final_layer
+    key = tuple((t.data_ptr(), t._version, str(t.device)) for t in (lin.weight, lin.bias))
+    cache = coupling.__dict__.setdefault('_fused_final_pack', {})
+    if cache.get('key') != key:
+        cache['key'] = key
+        with torch.no_grad():
+            buf = pack(lin.weight.detach(), lin.bias.detach(), coupling.num_transform_features, coupling.num_bins)
+        old = cache.get('buf')
+        if old is not None and old.shape == buf.shape and old.device == buf.device:
+            old.copy_(buf)
+        else:
+            cache['buf'] = buf
+    want = int(_lib.lib().vcnf_rqs_final_fused_pack_floats(coupling.num_transform_features,
+                                                           coupling.transform_net.hidden_features, coupling.num_bins))
+    assert cache['buf'].numel() == want, (cache['buf'].numel(), want)
+    return cache['buf']
+
+
+def run(coupling, inputs, context, sampling, log_q=None, sign=1.0):
+    """Coupling layer with the conditioner trunk on PyTorch-ROCm and last layer + splines in one
+    kernel; same (out, log_det) contract as PiecewiseRationalQuadraticCoupling._run."""
+    net = coupling.transform_net
+    uncond = coupling.unconditional_transform
+    xi = inputs[:, coupling.identity_features]
+    lad_i = None
+    if uncond is not None and sampling:                 # coupling.py:110-114: the conditioner sees S^-1(x_id)
+        xi, lad_i = uncond.inverse(xi)
+    h = net.hidden(xi if context is None else torch.cat((xi, context), dim=1), context)
+    if uncond is not None and not sampling:
+        xi, lad_i = uncond.forward(xi)
+    out = torch.empty_like(inputs)
+    out[:, coupling.identity_features] = xi
+    partial = _lib.rqs_final_fused(inputs, h, out, coupling._index32('tf'), coupling.num_transform_features,
+                                   net.hidden_features, packed_weights(coupling), coupling._cfg(True), sampling)
+    lad = partial.sum(0) if partial.shape[0] > 1 else partial[0]
+    if lad_i is not None:
+        lad = lad + lad_i
+    if log_q is not None:
+        return out, log_q.add_(lad, alpha=sign)
+    return out, (lad if sign == 1.0 else sign * lad)

@@ -68,6 +68,15 @@ class ResidualNet(nn.Module):
             h = torch.cat((h, context), dim=1)
         return self.trunk(h, context)
 
+    def hidden(self, first_in, context=None):
+        """Output of the last residual block (the input of ``final_layer``) for an already
+        concatenated (identity | context) input; the last layer itself can then run inside the
+        spline kernel (csrc/fused_final.hip)."""
+        h = self.initial_layer(first_in)
+        for block in self.blocks:
+            h = block(h, context=context)
+        return h
+
     def trunk(self, first_in, context=None):
         """Everything after the (identity | context) concatenation; the RQS
         coupling calls this directly with the buffer its gather kernel wrote."""
