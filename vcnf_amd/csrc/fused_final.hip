@@ -111,36 +111,58 @@ __global__ __launch_bounds__(kFinBlock, 2) void rqs_final_fused_kernel(const Fin
 #pragma unroll
         for (int b = 0; b < P4; ++b)
           pa[b] = *reinterpret_cast<const floatx4*>(bias + ((long long)g * 4 + q) * (4 * P4) + 4 * b);
-        // two row blocks advance together: six independent accumulator updates per k-step
+        // this lane's input element of the group: requested before the matrix work
+        const int f = 4 * g + q;
+        const bool live = valid && f < a.d_t;
+        const long long at = live ? row * a.D + a.tf_idx[f] : 0;
+        const float xv = live ? a.x[at] : 0.f;
+        // two row blocks advance together (six independent accumulator updates per k-step); the four
+        // weight fragments of step u + 1 are read from LDS before the matrix instructions of step u
+        {
+          constexpr int NSTEP = (P4 / 2) * NS;
+          half8 whi[2][2], wlo[2][2];          // [slot][row block of the pair]
+          floatx4 mainv[2], corr[2];
+#define VCNF_FF_READ(U)                                                                      \
+  _Pragma("unroll") for (int bb = 0; bb < 2; ++bb) {                                         \
+    whi[(U) & 1][bb] = __builtin_bit_cast(half8, win[(((2 * ((U) / NS) + bb) * NS + ((U) % NS)) * 2 + 0) * 64 + lane]); \
+    wlo[(U) & 1][bb] = __builtin_bit_cast(half8, win[(((2 * ((U) / NS) + bb) * NS + ((U) % NS)) * 2 + 1) * 64 + lane]); \
+  }
+          VCNF_FF_READ(0)
 #pragma unroll
-        for (int bp = 0; bp < P4; bp += 2) {
-          floatx4 mainv[2] = {pa[bp], pa[bp + 1]};
-          floatx4 corr[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            half8 whi[2], wlo[2];
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-              whi[bb] = __builtin_bit_cast(half8, win[(((bp + bb) * NS + s) * 2 + 0) * 64 + lane]);
-              wlo[bb] = __builtin_bit_cast(half8, win[(((bp + bb) * NS + s) * 2 + 1) * 64 + lane]);
+          for (int u = 0; u < NSTEP; ++u) {
+            const int bp = 2 * (u / NS), s = u % NS;
+            if (u + 1 < NSTEP) {
+              VCNF_FF_READ(u + 1)
+            }
+            if (s == 0) {
+              mainv[0] = pa[bp];
+              mainv[1] = pa[bp + 1];
+              corr[0] = corr[1] = floatx4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) mainv[bb] = mfma16h(whi[bb], fhi[s], mainv[bb]);
+            for (int bb = 0; bb < 2; ++bb) mainv[bb] = mfma16h(whi[u & 1][bb], fhi[s], mainv[bb]);
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) corr[bb] = mfma16h(whi[bb], flo[s], corr[bb]);
+            for (int bb = 0; bb < 2; ++bb) corr[bb] = mfma16h(whi[u & 1][bb], flo[s], corr[bb]);
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) corr[bb] = mfma16h(wlo[bb], fhi[s], corr[bb]);
+            for (int bb = 0; bb < 2; ++bb) corr[bb] = mfma16h(wlo[u & 1][bb], fhi[s], corr[bb]);
+            if (s == NS - 1) {
+#pragma unroll
+              for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pa[bp + bb][r] = fmaf(corr[bb][r], kLoUnscale, mainv[bb][r]);
+            }
           }
+#undef VCNF_FF_READ
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-          for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pa[bp + bb][r] = fmaf(corr[bb][r], kLoUnscale, mainv[bb][r]);
+          for (int u = 0; u + 1 < NSTEP; ++u) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
         }
         // ---- one spline per lane: sample `row`, transformed feature 4 g + q
-        const int f = 4 * g + q;
-        if (valid && f < a.d_t) {
-          const long long at = row * a.D + a.tf_idx[f];
-          const float xv = a.x[at];
+        if (live) {
           RegLogits<K, P4> p{pa, c.wh_scale, c.edge_logit};
           float yv, lad;
           if (c.tails == 1 && !((xv >= c.lo_x) && (xv <= c.hi_x))) {
