@@ -54,6 +54,15 @@ def conv_residual_net(sd, prefix, x, context=None, activation=F.relu):
     return conv(prefix + "final_layer", h, 0)               # :211
 
 
+def periodic_features(sd, prefix, x, scale):
+    """utils/nn.py:111-118: columns ``ind`` -> w0 sin(scale x) + w1 cos(scale x), others unchanged."""
+    ind, rest, inv_perm = sd[prefix + "ind"], sd[prefix + "ind_"], sd[prefix + "inv_perm"]
+    w = sd[prefix + "weights"]
+    a = scale * x[..., ind]
+    a = w[:, 0] * torch.sin(a) + w[:, 1] * torch.cos(a)
+    return torch.cat((a, x[..., rest]), -1)[..., inv_perm]
+
+
 def mlp(sd, prefix, x, leaky=0.0):
     """mlp.py:30-35,55-58 without output_fn: Linear, LeakyReLU, ..., Linear.
     Linear layers sit at even positions of ``net`` (keys ``net.{2k}``)."""

@@ -628,6 +628,47 @@ def g17_image_rqs():
     save("g17_image_rqs", **out)
 
 
+# ---------------------------------------------------------------- G18
+def g18_per_feature_tails():
+    """Per-feature tails and tensor tail bounds (splines.py:50-66) on the functional spline, and the
+    circular NSF layer (wrapper.py:90-187) with periodic features in its conditioner."""
+    out = {}
+    k, d = 8, 6
+    tails = ["linear", "circular", "linear", "circular", "circular", "linear"]
+    bound = torch.tensor([2.0, float(np.pi), 3.0, float(np.pi), 1.5, 2.0])
+    r = rng(1800)
+    x = torch.from_numpy((1.6 * r.standard_normal((256, d))).astype(np.float32))
+    uw, uh = (torch.from_numpy(r.standard_normal((256, d, k)).astype(np.float32)) for _ in range(2))
+    ud = torch.from_numpy(r.standard_normal((256, d, k + 1)).astype(np.float32))
+    out["fn/x"], out["fn/uw"], out["fn/uh"], out["fn/ud"], out["fn/bound"] = npy(x), npy(uw), npy(uh), npy(ud), npy(bound)
+    for inv in (False, True):
+        def f(a, b, c, e):
+            return ref_splines.unconstrained_rational_quadratic_spline(a, b, c, e, inverse=inv, tails=tails,
+                                                                       tail_bound=bound.to(a.dtype))
+        (y32, l32), (y64, l64) = both(f, x, uw, uh, ud)
+        tag = "fn/" + ("inv" if inv else "fwd")
+        out[tag + "/y32"], out[tag + "/ld32"], out[tag + "/y64"], out[tag + "/ld64"] = npy(y32), npy(l32), npy(y64), npy(l64)
+    dd = 7
+    lb = torch.tensor([float(np.pi), 2.5, 2.5, float(np.pi), float(np.pi), 2.0, 2.5])
+    # inputs strictly inside every bound used below: with a tails LIST the reference leaves outputs of
+    # outside elements at zero (splines.py:50-57 has no identity assignment), which would then feed
+    # the conditioner; the functional case above documents that on purpose, the layer case avoids it
+    u = torch.from_numpy(r.random((256, dd), dtype=np.float32))
+    xl = (2 * u - 1) * 0.95 * torch.minimum(lb, torch.tensor(3.0))
+    out["layer/x"] = npy(xl)
+    out["layer/bound"] = npy(lb)
+    for tagb, tb in (("scalar", 3.0), ("tensor", lb)):
+        # coordinates 0, 3, 4 are angles: 0 and 4 sit in the identity half (periodic features), 3 is transformed
+        build = lambda: nf.flows.CircularCoupledRationalQuadraticSpline(dd, 1, 32, ind_circ=[0, 3, 4], num_bins=k,
+                                                                        tail_bound=tb, init_identity=False)
+        call = lambda m, a: m.forward(a) + m.inverse(a)
+        keep = ("prqct.tail_bound", "prqct.unconditional_transform.tail_bound",
+                "prqct.transform_net.preprocessing.scale")          # constructor values, not synthetic ones
+        ents, ints, o32, o64, _ = run_module_case(build, 1801, [xl], call, skip=keep, final_gain=2.0)
+        pack(out, "layer/" + tagb, ents, ints, ["fwd_z", "fwd_ld", "inv_z", "inv_ld"], o32, o64)
+    save("g18_per_feature_tails", **out)
+
+
 if __name__ == "__main__":
     g1_rqs()
     g2_tails()
@@ -646,3 +687,4 @@ if __name__ == "__main__":
     g15_checkerboard()
     g16_circular()
     g17_image_rqs()
+    g18_per_feature_tails()

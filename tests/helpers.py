@@ -56,6 +56,34 @@ def oracle_image_rqs_coupling(sd, num_bins=8, tail_bound=3.0, hidden=16):
                           hidden_features=hidden, uncond=uncond)
 
 
+def oracle_circular_layer(sd, num_features, ind_circ, tail_bound, num_bins=8, hidden=32):
+    """Oracle CircularCoupledRationalQuadraticSpline (wrapper.py:90-187): per-feature tails / bounds split
+    over the two halves (coupling.py:264-298), periodic features in front of the conditioner."""
+    idf, tf = sd["prqct.identity_features"], sd["prqct.transform_features"]
+    tails = ["circular" if i in ind_circ else "linear" for i in range(num_features)]
+    dt = sd["prqct.transform_net.initial_layer.weight"].dtype
+    if torch.is_tensor(tail_bound):
+        tb = tail_bound.to(dt)
+        tb_id, tb_tf = tb[idf], tb[tf]
+        circ_id = [p for p, f in enumerate(idf.tolist()) if f in ind_circ]
+        # wrapper.py:143: the full tensor indexed by positions in the identity half, evaluated in the
+        # tensor's own dtype at construction (a later .double() converts the rounded value)
+        scale = (np.pi / tail_bound[circ_id]).to(dt)
+    else:
+        tb_id = tb_tf = tail_bound
+        scale = np.pi / tail_bound
+    u = "prqct.unconditional_transform."
+    uncond = OL.RQSCDF(sd[u + "unnormalized_widths"], sd[u + "unnormalized_heights"], sd[u + "unnormalized_derivatives"],
+                       [tails[i] for i in idf.tolist()], tb_id)
+    pre = "prqct.transform_net."
+
+    def cond(x, ctx):
+        x = ON.periodic_features(sd, pre + "preprocessing.", x, scale) if (pre + "preprocessing.ind") in sd else x
+        return ON.residual_net(sd, pre, x, None, F.relu)
+    return OL.RQSCoupling(idf, tf, cond, num_bins, [tails[i] for i in tf.tolist()], tb_tf, hidden_features=hidden,
+                          uncond=uncond)
+
+
 def oracle_c3_stack(sd, layers=12, num_bins=8, tail_bound=3.0, hidden=128):
     flows = [oracle_rqs_coupling(sd, "flows.%d.prqct." % i, num_bins, tail_bound, hidden)
              for i in range(layers)]

@@ -996,3 +996,52 @@ def test_final_layer_fused_with_splines(hip, d, k, blocks, ctx_dim, batch):
         zi, ldi = lay.inverse(dev(x), cg)
         assert torch.equal(z3, zi) and torch.allclose(lq, 0.5 + ldi, rtol=1e-6, atol=1e-5)
     nf.check_discriminant()
+
+
+# ---------------------------------------------------------------- next row: per-feature tails / bounds (G18)
+@pytest.mark.parametrize("inv", [False, True])
+def test_g18_per_feature_tails_functional(hip, inv):
+    """Tails per feature + a tensor of per-feature bounds (splines.py:50-66), evaluated group by group.
+    Deliberate deviation: elements outside their bound pass through (identity, zero log-det) as with
+    uniform tails; the reference leaves their OUTPUT at zero when tails is a list (no assignment in
+    splines.py:50-57)."""
+    fx = fixture("g18_per_feature_tails")
+    tails = ["linear", "circular", "linear", "circular", "circular", "linear"]
+    tag = "fn/" + ("inv" if inv else "fwd")
+    x, uw, uh, ud = (dev(T(fx["fn/" + n])) for n in ("x", "uw", "uh", "ud"))
+    bound = dev(T(fx["fn/bound"]))
+    with torch.no_grad():
+        y, ld = nf.utils.splines.unconstrained_rational_quadratic_spline(x, uw, uh, ud, inverse=inv, tails=tails,
+                                                                         tail_bound=bound)
+    inside = ((x >= -bound) & (x <= bound)).cpu()
+    y32, y64, l32, l64 = (T(fx[tag + "/" + n]) for n in ("y32", "y64", "ld32", "ld64"))
+    parity(y.cpu()[inside], y32[inside], y64[inside], what="y inside")
+    parity(ld.cpu()[inside], l32[inside], l64[inside], what="ld inside")
+    assert torch.equal(y.cpu()[~inside], x.cpu()[~inside]) and not ld.cpu()[~inside].any()
+    assert not y32[~inside].any()                      # the reference's zeros, documented above
+    nf.check_discriminant()
+
+
+@pytest.mark.parametrize("kind", ["scalar", "tensor"])
+def test_g18_circular_coupled_layer(hip, kind):
+    fx = fixture("g18_per_feature_tails")
+    sd, _ = state_for(fx, "layer/" + kind, 1801, final_gain=2.0)
+    tb = 3.0 if kind == "scalar" else T(fx["layer/bound"])
+    lay = nf.flows.CircularCoupledRationalQuadraticSpline(7, 1, 32, ind_circ=[0, 3, 4], num_bins=8, tail_bound=tb,
+                                                          init_identity=False)
+    lay.load_state_dict(sd, strict=False)              # tail-bound / scale buffers keep their constructor values
+    missing = set(lay.state_dict()) - set(sd)
+    assert all(("tail_bound" in m) or m.endswith("preprocessing.scale") for m in missing), missing
+    lay = lay.cuda()
+    x = dev(T(fx["layer/x"]))
+    with torch.no_grad():
+        for dirn, fn in (("fwd", lay.forward), ("inv", lay.inverse)):
+            z, ld = fn(x)
+            parity(z, fx["layer/%s/%s_z32" % (kind, dirn)], fx["layer/%s/%s_z64" % (kind, dirn)], what=dirn + " z")
+            parity(ld, fx["layer/%s/%s_ld32" % (kind, dirn)], fx["layer/%s/%s_ld64" % (kind, dirn)], rtol=1e-5,
+                   atol=2e-5, what=dirn + " ld")
+    nf.check_discriminant()
+    # training path through the per-feature layer
+    loss = lay.inverse(x)[1].mean()
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in lay.parameters())

@@ -304,3 +304,30 @@ def test_g17_image_rqs_coupling(tag):
             z, ld = fn(x, ctx)
             assert_close(z, fx["%s/%s_z%s" % (tag, dirn, suf)], what=dirn + " z", **tol)
             assert_close(ld, fx["%s/%s_ld%s" % (tag, dirn, suf)], what=dirn + " ld", **tol)
+
+
+@pytest.mark.parametrize("inv", [False, True])
+def test_g18_per_feature_tails_functional(inv):
+    fx = fixture("g18_per_feature_tails")
+    tails = ["linear", "circular", "linear", "circular", "circular", "linear"]
+    tag = "fn/" + ("inv" if inv else "fwd")
+    for dt, suf, tol in ((torch.float32, "32", F32), (torch.float64, "64", F64)):
+        args = [T(fx["fn/" + n], dt) for n in ("x", "uw", "uh", "ud")]
+        y, ld = OR.rq_spline_tails(*args, inverse=inv, tails=tails, tail_bound=T(fx["fn/bound"], dt))
+        assert_close(y, fx[tag + "/y" + suf], what="y", **tol)
+        assert_close(ld, fx[tag + "/ld" + suf], what="ld", **tol)
+
+
+@pytest.mark.parametrize("kind", ["scalar", "tensor"])
+def test_g18_circular_coupled_layer(kind):
+    from helpers import oracle_circular_layer
+    fx = fixture("g18_per_feature_tails")
+    for dt, suf, tol in ((torch.float32, "32", dict(rtol=2e-5, atol=2e-5)), (torch.float64, "64", F64)):
+        sd, _ = state_for(fx, "layer/" + kind, 1801, dt, final_gain=2.0)
+        tb = 3.0 if kind == "scalar" else T(fx["layer/bound"])
+        lay = oracle_circular_layer(sd, 7, [0, 3, 4], tb)
+        x = T(fx["layer/x"], dt)
+        for dirn, fn in (("fwd", lay.forward), ("inv", lay.inverse)):
+            z, ld = fn(x)
+            assert_close(z, fx["layer/%s/%s_z%s" % (kind, dirn, suf)], what=dirn + " z", **tol)
+            assert_close(ld, fx["layer/%s/%s_ld%s" % (kind, dirn, suf)], what=dirn + " ld", **tol)

@@ -6,4 +6,5 @@ from .affine import (AffineConstFlow, AffineCoupling, MaskedAffineFlow,         
                      AffineCouplingBlock)
 from .affine.glow import GlowBlock                                                # noqa: F401
 from .neural_spline import (CoupledRationalQuadraticSpline,                       # noqa: F401
+                            CircularCoupledRationalQuadraticSpline,
                             PiecewiseRationalQuadraticCoupling, PiecewiseRationalQuadraticCDF)

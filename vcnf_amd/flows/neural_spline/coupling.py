@@ -37,10 +37,14 @@ class PiecewiseRationalQuadraticCDF(Flow):
         self.min_bin_height = min_bin_height
         self.min_derivative = min_derivative
         if torch.is_tensor(tail_bound):
-            raise NotImplementedError("tensor tail bounds are not built (SURVEY 8f row 4)")
-        self.tail_bound = tail_bound
+            self.register_buffer('tail_bound', tail_bound)        # coupling.py:180-181
+        else:
+            self.tail_bound = tail_bound
         self.tails = tails
         self.num_bins = num_bins
+        self.per_feature = isinstance(tails, (list, tuple)) or torch.is_tensor(tail_bound)
+        if self.per_feature and len(list(shape)) != 1:
+            raise NotImplementedError("per-feature tails / tail bounds cover [B, features] inputs")
         if tails == 'linear':
             n_deriv = num_bins - 1
         elif tails == 'circular':
@@ -66,7 +70,34 @@ class PiecewiseRationalQuadraticCDF(Flow):
                              min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                              min_derivative=self.min_derivative)
 
+    def _spline_per_feature(self, inputs, inverse):
+        """Tails given per feature and / or per-feature bounds (splines.py:50-66): one call of the
+        batch-shared spline per group of features with the same (kind, bound)."""
+        k = self.num_bins
+        listed = isinstance(self.tails, (list, tuple))
+        out = torch.empty_like(inputs)
+        lad = 0.0
+        grad = autograd.needs_grad(inputs, *self.logits())
+        for kind, bound, idx in splines.feature_groups(self.tails, self.tail_bound, inputs.shape[1]):
+            ix = torch.as_tensor(idx, device=inputs.device)
+            cfg = _lib.make_cfg(k, kind, tail_bound=bound, min_bin_width=self.min_bin_width,
+                                min_bin_height=self.min_bin_height, min_derivative=self.min_derivative)
+            sl = splines.derivative_slice(kind, k) if listed else slice(None)
+            args = (inputs.index_select(1, ix).contiguous(), self.unnormalized_widths[ix],
+                    self.unnormalized_heights[ix], self.unnormalized_derivatives[ix][:, sl])
+            if grad:
+                y, ld = autograd.rqs_shared(*args, cfg, inverse=inverse)
+                out = out.index_copy(1, ix, y)
+            else:
+                y, le = _lib.rqs_elementwise_shared(*args, cfg, inverse)
+                ld = le.sum(1)
+                out.index_copy_(1, ix, y)
+            lad = lad + ld
+        return out, lad
+
     def _spline(self, inputs, inverse):
+        if self.per_feature:
+            return self._spline_per_feature(inputs, inverse)
         if tuple(inputs.shape[1:]) != tuple(self.unnormalized_widths.shape[:-1]):
             raise ValueError('Expected inputs of shape [B, {}], got {}.'.format(
                 tuple(self.unnormalized_widths.shape[:-1]), tuple(inputs.shape)))
@@ -101,30 +132,41 @@ class PiecewiseRationalQuadraticCoupling(Flow):
             raise ValueError('Mask must be a 1-dim tensor.')
         if mask.numel() <= 0:
             raise ValueError('Mask can\'t be empty.')
-        if isinstance(tails, (list, tuple)) or torch.is_tensor(tail_bound):
-            raise NotImplementedError("per-feature tails / tensor tail bounds are not built (SURVEY 8f row 4)")
-        if tails not in (None, 'linear', 'circular'):
+        per_feature = isinstance(tails, (list, tuple)) or torch.is_tensor(tail_bound)
+        if not per_feature and tails not in (None, 'linear', 'circular'):
             raise RuntimeError('{} tails are not implemented.'.format(tails))
+        if per_feature and img_shape:
+            raise NotImplementedError("per-feature tails / tail bounds cover [B, features] inputs")
         super().__init__()
+        self.per_feature = per_feature
         self.img_shape = list(img_shape) if img_shape else None
         self.num_bins = num_bins
         self.min_bin_width = min_bin_width
         self.min_bin_height = min_bin_height
         self.min_derivative = min_derivative
-        self.tails = tails
-        self.tail_bound = tail_bound
         self.features = len(mask)
         positions = torch.arange(self.features)
         self.register_buffer('identity_features', positions.masked_select(mask <= 0))
         self.register_buffer('transform_features', positions.masked_select(mask > 0))
+        # coupling.py:264-278, :297-298: per-feature tails / bounds are split over the two halves
+        id_tails, id_bound = tails, tail_bound
+        if isinstance(tails, (list, tuple)):
+            id_tails = [tails[int(i)] for i in self.identity_features]
+            tails = [tails[int(i)] for i in self.transform_features]
+        if torch.is_tensor(tail_bound):
+            id_bound = tail_bound[self.identity_features]
+            self.register_buffer('tail_bound', tail_bound[self.transform_features])
+        else:
+            self.tail_bound = tail_bound
+        self.tails = tails
         if self.num_transform_features == 0:
             raise ValueError('Mask selects no feature to transform.')
         self.transform_net = transform_net_create_fn(
             self.num_identity_features, self.num_transform_features * self._transform_dim_multiplier())
         if apply_unconditional_transform:
             self.unconditional_transform = PiecewiseRationalQuadraticCDF(
-                shape=[self.num_identity_features] + (self.img_shape or []), num_bins=num_bins, tails=tails,
-                tail_bound=tail_bound, min_bin_width=min_bin_width,
+                shape=[self.num_identity_features] + (self.img_shape or []), num_bins=num_bins, tails=id_tails,
+                tail_bound=id_bound, min_bin_width=min_bin_width,
                 min_bin_height=min_bin_height, min_derivative=min_derivative)
         else:
             self.unconditional_transform = None
@@ -149,7 +191,7 @@ class PiecewiseRationalQuadraticCoupling(Flow):
             return self.num_bins * 3 - 1
         if self.tails == 'circular':
             return self.num_bins * 3
-        return self.num_bins * 3 + 1
+        return self.num_bins * 3 + 1        # no tails, or a per-feature list (K+1 derivative logits each)
 
     # ------------------------------------------------------------ helpers
     def _index32(self, which):
@@ -264,8 +306,42 @@ class PiecewiseRationalQuadraticCoupling(Flow):
         out[:, self.transform_features] = yt
         return out, lad
 
+    def _run_per_feature(self, inputs, context, sampling):
+        """Per-feature tails / bounds (the circular NSF layers, wrapper.py:90-187): the coupling of
+        coupling.py:70-125 with both spline families evaluated group by group
+        (utils.splines.feature_groups)."""
+        if inputs.dim() != 2:
+            raise NotImplementedError("per-feature tails / tail bounds cover [B, features] inputs")
+        k = self.num_bins
+        uncond = self.unconditional_transform
+        xi = inputs[:, self.identity_features]
+        xt = inputs[:, self.transform_features]
+        lad = 0.0
+        if sampling and uncond is not None:
+            xi, lad = uncond.inverse(xi)
+        params = self.transform_net(xi, context) if context is not None else self.transform_net(xi)
+        p = params.reshape(inputs.shape[0], self.num_transform_features, -1)
+        scale = self._logit_scale()
+        yt, le = splines.unconstrained_rational_quadratic_spline(
+            xt, p[..., :k] * scale, p[..., k:2 * k] * scale, p[..., 2 * k:], inverse=sampling, tails=self.tails,
+            tail_bound=self.tail_bound, min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+            min_derivative=self.min_derivative)
+        lad = lad + le.sum(1)
+        if (not sampling) and uncond is not None:
+            xi, l2 = uncond.forward(xi)
+            lad = lad + l2
+        out = torch.empty_like(inputs)
+        out[:, self.identity_features] = xi
+        out[:, self.transform_features] = yt
+        return out, lad
+
     def _run(self, inputs, context, sampling, log_q=None, sign=1.0):
         self._check(inputs)
+        if self.per_feature:
+            out, lad = self._run_per_feature(inputs, context, sampling)
+            if log_q is not None:
+                return out, log_q.add_(lad, alpha=sign)
+            return out, (lad if sign == 1.0 else sign * lad)
         if inputs.dim() == 4:
             out, lad = self._run_image(inputs, context, sampling)
             if log_q is not None:
