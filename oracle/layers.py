@@ -236,6 +236,48 @@ class AffineCouplingBlock:
         return self._run(z, True)
 
 
+class AutoregressiveRQS:
+    """neural_spline/autoregressive.py:92-136 on top of affine/autoregressive.py:24-36: ``nsf_forward``
+    (density) is one conditioner pass, ``nsf_inverse`` (sampling) D passes from zeros.  ``conditioner(x)``
+    returns [B, D * P]; the reference's MADE has no ``hidden_features`` attribute, so the width / height
+    logits are NOT scaled (:104-106)."""
+
+    def __init__(self, conditioner, features, num_bins, tails, tail_bound,
+                 min_bin_width=rqs.MIN_BIN_WIDTH, min_bin_height=rqs.MIN_BIN_HEIGHT,
+                 min_derivative=rqs.MIN_DERIVATIVE):
+        self.conditioner, self.d, self.k = conditioner, features, num_bins
+        self.tails, self.tail_bound = tails, tail_bound
+        self.mins = (min_bin_width, min_bin_height, min_derivative)
+
+    def _elementwise(self, x, params, inverse):
+        p = params.view(x.shape[0], self.d, -1)                                     # :95-99
+        uw, uh, ud = p[..., :self.k], p[..., self.k:2 * self.k], p[..., 2 * self.k:]
+        kw = dict(inverse=inverse, min_bin_width=self.mins[0], min_bin_height=self.mins[1],
+                  min_derivative=self.mins[2])
+        if self.tails is None:
+            y, lad = rqs.rq_spline(x, uw, uh, ud, **kw)
+        else:
+            y, lad = rqs.rq_spline_tails(x, uw, uh, ud, tails=self.tails, tail_bound=self.tail_bound, **kw)
+        return y, _row_sum(lad)
+
+    def nsf_forward(self, x):
+        return self._elementwise(x, self.conditioner(x), False)
+
+    def nsf_inverse(self, x):
+        out, lad = torch.zeros_like(x), None
+        for _ in range(int(np.prod(x.shape[1:]))):                                  # affine/autoregressive.py:30-35
+            out, lad = self._elementwise(x, self.conditioner(out), True)
+        return out, lad
+
+    def forward(self, z):                                                           # wrapper.py:251-253
+        y, ld = self.nsf_inverse(z)
+        return y, ld.view(-1)
+
+    def inverse(self, z):
+        y, ld = self.nsf_forward(z)
+        return y, ld.view(-1)
+
+
 class LULinearPermute:
     """mixing.py:352-492: fixed permutation + linear map y = x (L U)^T + bias, L unit lower,
     diag(U) = softplus(.) + eps.  ``forward`` (sampling direction) = inverse linear map by two

@@ -5,6 +5,7 @@ layers whose outputs parameterise the bijector.
 * ``residual_net`` <- ``normflow/nets/resnet.py`` ResidualNet :60-106,
   ResidualBlock :8-57 (no batch norm, dropout p=0 -> identity)
 * ``conv_residual_net`` <- ``normflow/nets/resnet.py`` ConvResidualNet :163-212, ConvResidualBlock :109-160
+* ``made``         <- ``normflow/nets/made.py`` MADE :215-300, MaskedResidualBlock :138-212, MaskedLinear :79-80
 * ``mlp``          <- ``normflow/nets/mlp.py`` MLP :7-58 (Linear + LeakyReLU)
 """
 import torch
@@ -61,6 +62,29 @@ def periodic_features(sd, prefix, x, scale):
     a = scale * x[..., ind]
     a = w[:, 0] * torch.sin(a) + w[:, 1] * torch.cos(a)
     return torch.cat((a, x[..., rest]), -1)[..., inv_perm]
+
+
+def made(sd, prefix, x, context=None, activation=F.relu, preprocess=None):
+    """nets/made.py:292-300 (MADE.forward) with residual blocks :196-212: every Linear uses
+    weight * mask (:79-80); the masks are buffers of the state dict."""
+    def masked(key, t):
+        return F.linear(t, sd[key + ".weight"] * sd[key + ".mask"], sd[key + ".bias"])
+    h = x if preprocess is None else preprocess(x)
+    h = masked(prefix + "initial_layer", h)
+    if context is not None:
+        h = h + _lin(sd, prefix + "context_layer", context)
+    i = 0
+    while (prefix + "blocks.%d.linear_layers.0.weight" % i) in sd:
+        bp = prefix + "blocks.%d." % i
+        t = activation(h)
+        t = masked(bp + "linear_layers.0", t)
+        t = activation(t)
+        t = masked(bp + "linear_layers.1", t)
+        if context is not None:
+            t = F.glu(torch.cat((t, _lin(sd, bp + "context_layer", context)), dim=1), dim=1)
+        h = h + t
+        i += 1
+    return masked(prefix + "final_layer", h)
 
 
 def mlp(sd, prefix, x, leaky=0.0):

@@ -669,6 +669,49 @@ def g18_per_feature_tails():
     save("g18_per_feature_tails", **out)
 
 
+# ---------------------------------------------------------------- G19
+def g19_autoregressive():
+    """Autoregressive RQS layers (wrapper.py:197-330): MADE conditioner, density direction in one pass,
+    sampling direction in D sequential passes; plain (linear tails) and circular (per-feature tails,
+    periodic features, permuted degrees)."""
+    out = {}
+    d, k = 6, 8
+    r = rng(1900)
+    u = torch.from_numpy(r.random((192, d), dtype=np.float32))
+    x = (2 * u - 1) * 2.4
+    out["x"] = npy(x)
+    torch.manual_seed(1900)
+
+    def case(tag, build):
+        state = {}
+
+        def build_fixed():
+            m = build()
+            net = m.mprqat.autoregressive_net
+            # permuted degrees are drawn with torch.randperm: reuse the first draw for the fp64 twin
+            if "sd" in state:
+                for key, v in state["sd"].items():
+                    m.state_dict()[key].copy_(v)
+            else:
+                state["sd"] = {key: v.clone() for key, v in m.state_dict().items() if key.endswith(("mask", "degrees"))}
+            return m
+        call = lambda m, a: m.forward(a) + m.inverse(a)
+        probe = build_fixed()
+        keep = ("mprqat.tail_bound", "mprqat.autoregressive_net.preprocessing.scale") + tuple(
+            key for key in probe.state_dict() if key.endswith("mask"))   # masks are structure, stored below
+        ents, ints, o32, o64, m = run_module_case(build_fixed, 1901, [x], call, skip=keep, final_gain=2.0)
+        pack(out, tag, ents, ints, ["fwd_z", "fwd_ld", "inv_z", "inv_ld"], o32, o64)
+        for key, v in m.state_dict().items():
+            if key.endswith("mask"):
+                out[tag + "/mask/" + key] = npy(v)
+    case("plain", lambda: nf.flows.AutoregressiveRationalQuadraticSpline(d, 1, 32, num_bins=k, tail_bound=3.0,
+                                                                        init_identity=False))
+    case("circular", lambda: nf.flows.CircularAutoregressiveRationalQuadraticSpline(
+        d, 1, 32, ind_circ=[1, 4], num_bins=k, tail_bound=torch.tensor([3.0, float(np.pi), 3.0, 2.5, float(np.pi), 3.0]),
+        permute_mask=True, init_identity=False))
+    save("g19_autoregressive", **out)
+
+
 if __name__ == "__main__":
     g1_rqs()
     g2_tails()
@@ -688,3 +731,4 @@ if __name__ == "__main__":
     g16_circular()
     g17_image_rqs()
     g18_per_feature_tails()
+    g19_autoregressive()

@@ -1045,3 +1045,42 @@ def test_g18_circular_coupled_layer(hip, kind):
     loss = lay.inverse(x)[1].mean()
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in lay.parameters())
+
+
+# ---------------------------------------------------------------- next row: autoregressive RQS (G19)
+def _ar_layer(fx, tag):
+    if tag == "plain":
+        lay = nf.flows.AutoregressiveRationalQuadraticSpline(6, 1, 32, num_bins=8, tail_bound=3.0, init_identity=False)
+    else:
+        lay = nf.flows.CircularAutoregressiveRationalQuadraticSpline(
+            6, 1, 32, ind_circ=[1, 4], num_bins=8, tail_bound=torch.tensor([3.0, float(np.pi), 3.0, 2.5, float(np.pi), 3.0]),
+            permute_mask=True, init_identity=False)
+    sd, _ = state_for(fx, tag, 1901, final_gain=2.0)
+    for key, v in fx.items():
+        if key.startswith(tag + "/mask/"):
+            sd[key[len(tag) + 6:]] = T(v)
+    missing = lay.load_state_dict(sd, strict=False).missing_keys
+    assert all(("tail_bound" in m) or m.endswith("preprocessing.scale") for m in missing), missing
+    return lay.cuda()
+
+
+@pytest.mark.parametrize("tag", ["plain", "circular"])
+def test_g19_autoregressive_rqs(hip, tag):
+    """MADE conditioner on PyTorch-ROCm, splines on the packed kernel reading its [B, D*P] output in place:
+    density direction one pass, sampling direction D passes."""
+    fx = fixture("g19_autoregressive")
+    lay = _ar_layer(fx, tag)
+    x = dev(T(fx["x"]))
+    with torch.no_grad():
+        for dirn, fn in (("fwd", lay.forward), ("inv", lay.inverse)):
+            z, ld = fn(x)
+            parity(z, fx["%s/%s_z32" % (tag, dirn)], fx["%s/%s_z64" % (tag, dirn)], what=dirn + " z")
+            parity(ld, fx["%s/%s_ld32" % (tag, dirn)], fx["%s/%s_ld64" % (tag, dirn)], rtol=1e-5, atol=2e-5,
+                   what=dirn + " ld")
+        z, ld = lay.forward(x)
+        back, ld2 = lay.inverse(z)
+        assert float((back - x).abs().mean()) < 2e-5 and float((ld + ld2).abs().mean()) < 1e-4
+    nf.check_discriminant()
+    loss = lay.inverse(x)[1].mean()                      # training path (density direction)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in lay.parameters())

@@ -254,3 +254,29 @@ def test_sharded_evaluator_micro_batches():
     assert calls == [256, 256, 256, 232]
     assert torch.equal(got, x.sum(1) + c.sum(1))
     assert abs(float(ev.mean_log_prob(x)) - float(x.sum(1).double().mean())) < 1e-9
+
+
+@pytest.mark.parametrize("tag", ["plain", "circular"])
+def test_made_masks_and_state_keys_match_reference_fixture(tag):
+    """MADE's masks and degrees (deterministic for permute_mask=False) and the state-dict key set of
+    the autoregressive spline layers against the reference's (fixture G19)."""
+    from helpers import fixture
+    fx = fixture("g19_autoregressive")
+    torch.manual_seed(0)
+    if tag == "plain":
+        lay = nf.flows.AutoregressiveRationalQuadraticSpline(6, 1, 32, num_bins=8, tail_bound=3.0)
+    else:
+        lay = nf.flows.CircularAutoregressiveRationalQuadraticSpline(
+            6, 1, 32, ind_circ=[1, 4], num_bins=8, tail_bound=torch.tensor([3.0, np.pi, 3.0, 2.5, np.pi, 3.0]))
+    ours = lay.state_dict()
+    ref_float = {n for n, _ in synth.decode_entries(fx[tag + "/entries"])}
+    ref_keys = ref_float | {k[len(tag) + 5:] for k in fx if k.startswith(tag + "/int/")} \
+        | {k[len(tag) + 6:] for k in fx if k.startswith(tag + "/mask/")}
+    extra = {k for k in ours if k.endswith("tail_bound") or k.endswith("preprocessing.scale")}
+    assert set(ours) - extra == ref_keys
+    if tag == "plain":                                   # no random permutation of the degrees
+        for k in fx:
+            if k.startswith("plain/mask/"):
+                assert np.array_equal(ours[k[len("plain/mask/"):]].numpy(), fx[k]), k
+            if k.startswith("plain/int/"):
+                assert np.array_equal(ours[k[len("plain/int/"):]].numpy(), fx[k]), k

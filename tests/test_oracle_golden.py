@@ -331,3 +331,34 @@ def test_g18_circular_coupled_layer(kind):
             z, ld = fn(x)
             assert_close(z, fx["layer/%s/%s_z%s" % (kind, dirn, suf)], what=dirn + " z", **tol)
             assert_close(ld, fx["layer/%s/%s_ld%s" % (kind, dirn, suf)], what=dirn + " ld", **tol)
+
+
+def _ar_state(fx, tag, dt):
+    sd, _ = state_for(fx, tag, 1901, dt, final_gain=2.0)
+    for key, v in fx.items():
+        if key.startswith(tag + "/mask/"):
+            sd[key[len(tag) + 6:]] = T(v, dt)
+    return sd
+
+
+def _oracle_ar(sd, tag, dt):
+    pre = "mprqat.autoregressive_net."
+    if tag == "plain":
+        return OL.AutoregressiveRQS(lambda x: ON.made(sd, pre, x), 6, 8, "linear", 3.0)
+    bound = torch.tensor([3.0, float(np.pi), 3.0, 2.5, float(np.pi), 3.0])
+    tails = ["circular" if i in (1, 4) else "linear" for i in range(6)]
+    scale = (np.pi / bound[[1, 4]]).to(dt)
+    pp = lambda x: ON.periodic_features(sd, pre + "preprocessing.", x, scale)
+    return OL.AutoregressiveRQS(lambda x: ON.made(sd, pre, x, preprocess=pp), 6, 8, tails, bound.to(dt))
+
+
+@pytest.mark.parametrize("tag", ["plain", "circular"])
+def test_g19_autoregressive_rqs(tag):
+    fx = fixture("g19_autoregressive")
+    for dt, suf, tol in ((torch.float32, "32", dict(rtol=2e-5, atol=2e-5)), (torch.float64, "64", F64)):
+        lay = _oracle_ar(_ar_state(fx, tag, dt), tag, dt)
+        x = T(fx["x"], dt)
+        for dirn, fn in (("fwd", lay.forward), ("inv", lay.inverse)):
+            z, ld = fn(x)
+            assert_close(z, fx["%s/%s_z%s" % (tag, dirn, suf)], what=dirn + " z", **tol)
+            assert_close(ld, fx["%s/%s_ld%s" % (tag, dirn, suf)], what=dirn + " ld", **tol)

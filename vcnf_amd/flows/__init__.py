@@ -6,5 +6,6 @@ from .affine import (AffineConstFlow, AffineCoupling, MaskedAffineFlow,         
                      AffineCouplingBlock)
 from .affine.glow import GlowBlock                                                # noqa: F401
 from .neural_spline import (CoupledRationalQuadraticSpline,                       # noqa: F401
-                            CircularCoupledRationalQuadraticSpline,
+                            CircularCoupledRationalQuadraticSpline, AutoregressiveRationalQuadraticSpline,
+                            CircularAutoregressiveRationalQuadraticSpline,
                             PiecewiseRationalQuadraticCoupling, PiecewiseRationalQuadraticCDF)

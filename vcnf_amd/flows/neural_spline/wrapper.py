@@ -98,3 +98,50 @@ class CircularCoupledRationalQuadraticSpline(Flow):
     def inverse(self, z):
         z, log_det = self.prqct(z)
         return z, log_det.view(-1)
+
+
+class AutoregressiveRationalQuadraticSpline(Flow):
+    """Autoregressive neural spline layer (wrapper.py:197-259): ``forward`` samples (D sequential
+    passes), ``inverse`` evaluates density (one pass)."""
+
+    def __init__(self, num_input_channels, num_blocks, num_hidden_channels, num_bins=8, tail_bound=3,
+                 activation=nn.ReLU, dropout_probability=0., permute_mask=False, init_identity=True):
+        super().__init__()
+        from .autoregressive import MaskedPiecewiseRationalQuadraticAutoregressive
+        self.mprqat = MaskedPiecewiseRationalQuadraticAutoregressive(
+            features=num_input_channels, hidden_features=num_hidden_channels, context_features=None,
+            num_bins=num_bins, tails='linear', tail_bound=tail_bound, num_blocks=num_blocks,
+            use_residual_blocks=True, random_mask=False, permute_mask=permute_mask, activation=activation(),
+            dropout_probability=dropout_probability, use_batch_norm=False, init_identity=init_identity)
+
+    def forward(self, z):
+        z, log_det = self.mprqat.inverse(z)
+        return z, log_det.view(-1)
+
+    def inverse(self, z):
+        z, log_det = self.mprqat(z)
+        return z, log_det.view(-1)
+
+
+class CircularAutoregressiveRationalQuadraticSpline(Flow):
+    """Autoregressive spline layer with circular coordinates ``ind_circ`` (wrapper.py:262-330)."""
+
+    def __init__(self, num_input_channels, num_blocks, num_hidden_channels, ind_circ, num_bins=8, tail_bound=3,
+                 activation=nn.ReLU, dropout_probability=0., permute_mask=True, init_identity=True):
+        super().__init__()
+        from .autoregressive import MaskedPiecewiseRationalQuadraticAutoregressive
+        circ = set(int(i) for i in ind_circ)
+        tails = ['circular' if i in circ else 'linear' for i in range(num_input_channels)]
+        self.mprqat = MaskedPiecewiseRationalQuadraticAutoregressive(
+            features=num_input_channels, hidden_features=num_hidden_channels, context_features=None,
+            num_bins=num_bins, tails=tails, tail_bound=tail_bound, num_blocks=num_blocks, use_residual_blocks=True,
+            random_mask=False, permute_mask=permute_mask, activation=activation(),
+            dropout_probability=dropout_probability, use_batch_norm=False, init_identity=init_identity)
+
+    def forward(self, z):
+        z, log_det = self.mprqat.inverse(z)
+        return z, log_det.view(-1)
+
+    def inverse(self, z):
+        z, log_det = self.mprqat(z)
+        return z, log_det.view(-1)
