@@ -84,22 +84,37 @@ __global__ __launch_bounds__(kFinBlock, 2) void rqs_final_fused_kernel(const Fin
 
   bool bad = false;
   const long long ncb = (a.B + 15) / 16;
-  for (long long cb = (long long)sb * 8 + wave; cb < ncb; cb += (long long)a.sblocks * 8) {
+  // the trunk rows of the NEXT column block travel while the current one is processed
+  const long long cstride = (long long)a.sblocks * 8;
+  float4 nh[2 * NS];
+#define VCNF_FF_FETCH(CB)                                                                   \
+  {                                                                                         \
+    const long long r_ = (CB) * 16 + m16;                                                   \
+    const float4* hr_ = reinterpret_cast<const float4*>(a.h) + (r_ < a.B ? r_ : 0) * (kFinH / 4) + 2 * q; \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                        \
+      nh[2 * s] = hr_[8 * s];                                                               \
+      nh[2 * s + 1] = hr_[8 * s + 1];                                                       \
+    }                                                                                       \
+  }
+  if ((long long)sb * 8 + wave < ncb) {
+    VCNF_FF_FETCH((long long)sb * 8 + wave)
+  }
+  for (long long cb = (long long)sb * 8 + wave; cb < ncb; cb += cstride) {
     const long long row = cb * 16 + m16;
     const bool valid = row < a.B;
     // ---- this lane's B-operand fragments: hidden units 32 s + 8 q .. + 7 of sample `row`, split hi/lo
     half8 fhi[NS], flo[NS];
-    {
-      const float4* hr = reinterpret_cast<const float4*>(a.h) + (valid ? row : 0) * (kFinH / 4) + 2 * q;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const float4 v0 = hr[8 * s], v1 = hr[8 * s + 1];
-        half4 h0, l0, h1, l1;
-        split4<false>(floatx4{v0.x, v0.y, v0.z, v0.w}, h0, l0);
-        split4<false>(floatx4{v1.x, v1.y, v1.z, v1.w}, h1, l1);
-        fhi[s] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-        flo[s] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-      }
+    for (int s = 0; s < NS; ++s) {
+      const float4 v0 = nh[2 * s], v1 = nh[2 * s + 1];
+      half4 h0, l0, h1, l1;
+      split4<false>(floatx4{v0.x, v0.y, v0.z, v0.w}, h0, l0);
+      split4<false>(floatx4{v1.x, v1.y, v1.z, v1.w}, h1, l1);
+      fhi[s] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+      flo[s] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    if (cb + cstride < ncb) {
+      VCNF_FF_FETCH(cb + cstride)
     }
     float ld = 0.f;
 #pragma unroll
@@ -182,6 +197,7 @@ __global__ __launch_bounds__(kFinBlock, 2) void rqs_final_fused_kernel(const Fin
     ld += __shfl_xor(ld, 32, 64);
     if (q == 0 && valid) a.partial[(long long)gb * a.B + row] = ld;
   }
+#undef VCNF_FF_FETCH
   if (INV && a.bad && bad) atomicAdd(a.bad, 1);
 }
 
