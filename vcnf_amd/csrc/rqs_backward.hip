@@ -134,22 +134,40 @@ __device__ __forceinline__ BinGrad bin_inverse_vjp(float u, float v0, const RqsB
   return o;
 }
 
-template <int KT, bool INV>
+// PACKED: logits and their gradients are rows of P contiguous floats in the same layout (conditioner
+// output, inner = 1).  A thread's row is 4 P bytes from its neighbour's, so direct accesses are 64
+// scattered 4-byte transfers per instruction (2.6 TB/s measured).  In this mode the workgroup's 256
+// rows - one contiguous block - travel through LDS with coalesced accesses in both directions: the
+// logits are staged, every thread reads and then overwrites ITS row in LDS (odd P: conflict free), and
+// the block of gradients leaves with coalesced stores.
+template <int KT, bool INV, bool PACKED>
 __global__ __launch_bounds__(kBwdBlock) void rqs_elementwise_bwd_kernel(const BwdArgs a) {
+  extern __shared__ float stage[];                 // PACKED: [kBwdBlock][P]
   const RqsConst& c = a.c;
   const int K = KT > 0 ? KT : c.K;
   constexpr int KA = KT > 0 ? KT : kBwdMaxK;
-  for (long long i = (long long)blockIdx.x * kBwdBlock + threadIdx.x; i < a.n; i += (long long)gridDim.x * kBwdBlock) {
+  const int P = 2 * K + a.nd;
+  for (long long base = (long long)blockIdx.x * kBwdBlock; base < a.n; base += (long long)gridDim.x * kBwdBlock) {
+    const long long i = base + threadIdx.x;
+    const bool active = i < a.n;
+    if (PACKED) {
+      const long long lim = (a.n - base < kBwdBlock ? a.n - base : kBwdBlock) * P;
+      const float* src = a.uw + base * P;
+      __syncthreads();                              // previous block of gradients has left
+      for (long long e = threadIdx.x; e < lim; e += kBwdBlock) stage[e] = src[e];
+      __syncthreads();
+    }
+    if (active) do {
     const float x = a.x[i];
     const float gy = a.gy[i], gl = a.glad[a.lad_div == 1 ? i : i / a.lad_div];
     const long long outer = a.inner == 1 ? i : i / a.inner, inn = a.inner == 1 ? 0 : i - outer * a.inner;
-    const long long ks = a.ks;
-    const float* uw = a.uw + outer * a.row_w + inn;
-    const float* uh = a.uh + outer * a.row_h + inn;
-    const float* ud = a.ud + outer * a.row_d + inn;
-    float* guw = a.guw + outer * a.grow_w + inn;
-    float* guh = a.guh + outer * a.grow_h + inn;
-    float* gud = a.gud + outer * a.grow_d + inn;
+    const long long ks = PACKED ? 1 : a.ks;
+    const float* uw = PACKED ? stage + threadIdx.x * P : a.uw + outer * a.row_w + inn;
+    const float* uh = PACKED ? uw + K : a.uh + outer * a.row_h + inn;
+    const float* ud = PACKED ? uw + 2 * K : a.ud + outer * a.row_d + inn;
+    float* guw = PACKED ? stage + threadIdx.x * P : a.guw + outer * a.grow_w + inn;
+    float* guh = PACKED ? guw + K : a.guh + outer * a.grow_h + inn;
+    float* gud = PACKED ? guw + 2 * K : a.gud + outer * a.grow_d + inn;
     if (c.tails != 0 && !((x >= c.lo_x) && (x <= c.hi_x))) {     // identity outside: dy/dx = 1
       a.gx[i] = gy;
       for (int k = 0; k < K; ++k) { guw[k * ks] = 0.f; guh[k * ks] = 0.f; }
@@ -232,6 +250,13 @@ __global__ __launch_bounds__(kBwdBlock) void rqs_elementwise_bwd_kernel(const Bw
     for (int k = 0; k < a.nd; ++k) gud[k * ks] = 0.f;
     if (has0) gud[i0 * ks] += g.gd0 * softplus_grad(l0);
     if (has1) gud[i1 * ks] += g.gd1 * softplus_grad(l1);        // circular, one bin: both knots share logit 0
+    } while (0);
+    if (PACKED) {
+      const long long lim = (a.n - base < kBwdBlock ? a.n - base : kBwdBlock) * P;
+      float* dst = a.guw + base * P;
+      __syncthreads();                              // every row of the block holds its gradient
+      for (long long e = threadIdx.x; e < lim; e += kBwdBlock) dst[e] = stage[e];
+    }
   }
 }
 
@@ -390,14 +415,15 @@ static int launch_shared_bwd(const SharedBwdArgs& a, dim3 grid, hipStream_t st) 
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }
 
-template <bool INV>
+template <bool INV, bool PACKED>
 static void launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t st) {
+  const size_t lds = PACKED ? (size_t)kBwdBlock * (2 * a.c.K + a.nd) * sizeof(float) : 0;
   switch (a.c.K) {
-    case 4: hipLaunchKernelGGL((rqs_elementwise_bwd_kernel<4, INV>), grid, dim3(kBwdBlock), 0, st, a); break;
-    case 8: hipLaunchKernelGGL((rqs_elementwise_bwd_kernel<8, INV>), grid, dim3(kBwdBlock), 0, st, a); break;
-    case 10: hipLaunchKernelGGL((rqs_elementwise_bwd_kernel<10, INV>), grid, dim3(kBwdBlock), 0, st, a); break;
-    case 16: hipLaunchKernelGGL((rqs_elementwise_bwd_kernel<16, INV>), grid, dim3(kBwdBlock), 0, st, a); break;
-    default: hipLaunchKernelGGL((rqs_elementwise_bwd_kernel<0, INV>), grid, dim3(kBwdBlock), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((rqs_elementwise_bwd_kernel<4, INV, PACKED>), grid, dim3(kBwdBlock), lds, st, a); break;
+    case 8: hipLaunchKernelGGL((rqs_elementwise_bwd_kernel<8, INV, PACKED>), grid, dim3(kBwdBlock), lds, st, a); break;
+    case 10: hipLaunchKernelGGL((rqs_elementwise_bwd_kernel<10, INV, PACKED>), grid, dim3(kBwdBlock), lds, st, a); break;
+    case 16: hipLaunchKernelGGL((rqs_elementwise_bwd_kernel<16, INV, PACKED>), grid, dim3(kBwdBlock), lds, st, a); break;
+    default: hipLaunchKernelGGL((rqs_elementwise_bwd_kernel<0, INV, PACKED>), grid, dim3(kBwdBlock), lds, st, a); break;
   }
 }
 
@@ -431,8 +457,20 @@ static int bwd_common(const vcnf_rqs_cfg* cfg, BwdArgs& a, int64_t n) {
 static int bwd_launch(const BwdArgs& a, int inverse, void* stream) {
   const long long blocks = (a.n + kBwdBlock - 1) / kBwdBlock;
   dim3 grid((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16));
-  if (inverse) launch_bwd<true>(a, grid, (hipStream_t)stream);
-  else launch_bwd<false>(a, grid, (hipStream_t)stream);
+  // rows of logits and of gradients packed alike and small enough for LDS: staged, coalesced variant
+  const long long P = 2 * a.c.K + a.nd;
+  const bool packed = a.inner == 1 && a.ks == 1 && a.row_w == P && a.row_h == P && a.row_d == P &&
+                      a.grow_w == P && a.grow_h == P && a.grow_d == P && a.uh == a.uw + a.c.K &&
+                      a.ud == a.uw + 2 * a.c.K && a.guh == a.guw + a.c.K && a.gud == a.guw + 2 * a.c.K &&
+                      (size_t)kBwdBlock * P * sizeof(float) <= 48 * 1024;
+  hipStream_t st = (hipStream_t)stream;
+  if (packed) {
+    if (inverse) launch_bwd<true, true>(a, grid, st);
+    else launch_bwd<false, true>(a, grid, st);
+  } else {
+    if (inverse) launch_bwd<true, false>(a, grid, st);
+    else launch_bwd<false, false>(a, grid, st);
+  }
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }
 
