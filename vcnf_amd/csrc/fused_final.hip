@@ -79,8 +79,22 @@ __global__ __launch_bounds__(kFinBlock, 2) void rqs_final_fused_kernel(const Fin
     const int have = min(GW, a.NG - g0) * GFRAG;
     for (int i = tid; i < GW * GFRAG; i += kFinBlock) wlds[i] = i < have ? src[i] : make_uint4(0u, 0u, 0u, 0u);
   }
+  // bias rows [group][q][4 P4] of the resident groups behind the weights in LDS; this lane's transformed
+  // column of each resident group in a register: neither changes over the launch, and a global load
+  // per group and column block sat exposed in front of every matrix phase
+  float* blds = reinterpret_cast<float*>(wlds + GW * GFRAG);
+  {
+    const float* bsrc = a.wpack + (long long)a.NG * GFRAG * 4 + (long long)g0 * 16 * P4;
+    const int have = min(GW, a.NG - g0) * 16 * P4;
+    for (int i = tid; i < GW * 16 * P4; i += kFinBlock) blds[i] = i < have ? bsrc[i] : 0.f;
+  }
+  int tcol[GW];
+#pragma unroll
+  for (int gi = 0; gi < GW; ++gi) {
+    const int f = 4 * (g0 + gi) + q;
+    tcol[gi] = f < a.d_t ? a.tf_idx[f] : -1;
+  }
   __syncthreads();
-  const float* bias = a.wpack + (long long)a.NG * GFRAG * 4;       // [NG][4][4 P4]
 
   bool bad = false;
   const long long ncb = (a.B + 15) / 16;
@@ -125,11 +139,10 @@ __global__ __launch_bounds__(kFinBlock, 2) void rqs_final_fused_kernel(const Fin
         floatx4 pa[P4];
 #pragma unroll
         for (int b = 0; b < P4; ++b)
-          pa[b] = *reinterpret_cast<const floatx4*>(bias + ((long long)g * 4 + q) * (4 * P4) + 4 * b);
+          pa[b] = *reinterpret_cast<const floatx4*>(blds + (gi * 4 + q) * (4 * P4) + 4 * b);
         // this lane's input element of the group: requested before the matrix work
-        const int f = 4 * g + q;
-        const bool live = valid && f < a.d_t;
-        const long long at = live ? row * a.D + a.tf_idx[f] : 0;
+        const bool live = valid && tcol[gi] >= 0;
+        const long long at = live ? row * a.D + tcol[gi] : 0;
         const float xv = live ? a.x[at] : 0.f;
         // two row blocks advance together (six independent accumulator updates per k-step); the four
         // weight fragments of step u + 1 are read from LDS before the matrix instructions of step u
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(kFinBlock, 2) void rqs_final_fused_kernel(const Fin
 template <int K>
 static int launch_final(const FinalArgs& a, int inverse, hipStream_t st) {
   using S = FinalShape<K>;
-  const size_t lds = (size_t)S::GW * S::GFRAG * 16;
+  const size_t lds = (size_t)S::GW * S::GFRAG * 16 + (size_t)S::GW * 16 * S::P4 * sizeof(float);
   static bool attr_set[2] = {false, false};
   if (!attr_set[inverse ? 1 : 0]) {
     hipError_t e = inverse
