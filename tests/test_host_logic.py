@@ -175,13 +175,21 @@ def test_no_cpu_fallback():
 
 
 def test_product_does_not_import_oracle():
+    """The package and the timing tools never import the oracle, the test helpers or a test module
+    (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may)."""
     import os, re
-    root = os.path.dirname(os.path.abspath(nf.__file__))
-    for dp, _, files in os.walk(root):
-        for f in files:
-            if f.endswith(".py"):
-                src = open(os.path.join(dp, f)).read()
-                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+    pkg = os.path.dirname(os.path.abspath(nf.__file__))
+    repo = os.path.dirname(pkg)
+    pat = re.compile(r"^\s*(from|import)\s+(oracle|helpers|test_\w+)\b", flags=re.M)
+    for root in (pkg, os.path.join(repo, "profiles", "tools")):
+        for dp, _, files in os.walk(root):
+            for f in files:
+                if f.endswith(".py"):
+                    src = open(os.path.join(dp, f)).read()
+                    assert not pat.search(src), os.path.join(dp, f)
+    bench = open(os.path.join(repo, "bench.py")).read()
+    body = bench.split("def cpu_baseline", 1)
+    assert not pat.search(body[0]), "bench.py reaches the oracle outside cpu_baseline"
 
 
 def test_shard_bounds_partition():
