@@ -196,11 +196,11 @@ int vcnf_rqs_conditioner_input_f32(const float* x, int64_t batch, int32_t featur
                                    float* out, void* stream);
 
 /* Packed conditioner weights of one fused RQS coupling layer: ONE device buffer of
- * vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim) floats (0: shape not supported) holding the ResidualNet's nn.Linear
+ * vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim, num_blocks) floats (0: shape not supported) holding the ResidualNet's nn.Linear
  * weights (nets/resnet.py:78-90) re-ordered into matrix-core fragments, in the order
  *   W0 | b0 | per block: WA | ba | WB | bb | (WC | bc if ctx_dim > 0) | WF | bf
  * (exact fragment order: vcnf_amd/fused.py::pack_layer, csrc/fused_layer.hip PackLayout). */
-int64_t vcnf_rqs_layer_fused_pack_floats(int32_t d_id, int32_t d_t, int32_t ctx_dim);
+int64_t vcnf_rqs_layer_fused_pack_floats(int32_t d_id, int32_t d_t, int32_t ctx_dim, int32_t num_blocks);
 
 /* 1 if vcnf_rqs_layer_fused_f32 has a kernel for this layer shape, else 0. */
 int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t ctx_dim, int32_t hidden,

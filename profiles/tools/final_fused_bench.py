@@ -13,7 +13,7 @@ def timeit(fn, n):
 
 with torch.no_grad():
     for name, d, k, blocks, c, layers, B in (("C5 layer stack", 1024, 16, 2, 0, 24, 16384),
-                                             ("D=64 K=8 3-block (outside the one-kernel family)", 64, 8, 3, 16, 12, 1 << 18),
+                                             ("D=48 K=8 3-block (d_id = 24: outside the one-kernel families)", 48, 8, 3, 16, 12, 1 << 18),
                                              ("D=128 K=16", 128, 16, 2, 0, 12, 1 << 17)):
         flows = [nf.flows.CoupledRationalQuadraticSpline(d, blocks, 128, k, reverse_mask=bool(i % 2), num_context_channels=c or None) for i in range(layers)]
         m = nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows).cuda()

@@ -102,7 +102,9 @@ def test_validation_status_codes_of_the_later_entry_points():
     assert L.vcnf_rqs_layer_fused_supported(16, 16, 0, 128, 2, 8, _lib.TAILS_LINEAR) == 1
     assert L.vcnf_rqs_layer_fused_supported(32, 32, 16, 128, 2, 8, _lib.TAILS_CIRCULAR) == 0
     assert L.vcnf_rqs_layer_fused_supported(24, 24, 0, 128, 2, 8, _lib.TAILS_LINEAR) == 0
-    assert L.vcnf_rqs_layer_fused_pack_floats(24, 24, 0) == 0
+    assert L.vcnf_rqs_layer_fused_pack_floats(24, 24, 0, 2) == 0
+    assert L.vcnf_rqs_layer_fused_supported(32, 32, 16, 128, 3, 8, _lib.TAILS_LINEAR) == 1
+    assert L.vcnf_rqs_layer_fused_supported(32, 32, 16, 128, 4, 8, _lib.TAILS_LINEAR) == 0
     assert L.vcnf_affine_layer_fused_supported(16, 64, 32, 32) == 1
     assert L.vcnf_affine_layer_fused_supported(16, 48, 32, 32) == 0          # hidden not in {32, 64, 128}
     assert L.vcnf_affine_layer_fused_supported(65, 64, 32, 130) == 0         # conditioner input too wide

@@ -87,7 +87,7 @@ def _check(ctx_dim):
         for p in net.parameters():
             p.normal_(0, 0.3)
     buf = fused.pack_layer(net, 32, 23).double().numpy()
-    assert len(buf) == nf.lib().vcnf_rqs_layer_fused_pack_floats(32, 32, ctx_dim)
+    assert len(buf) == nf.lib().vcnf_rqs_layer_fused_pack_floats(32, 32, ctx_dim, 2)
     x_id = torch.randn(16, 32, dtype=torch.float64)
     ctx = torch.randn(16, ctx_dim, dtype=torch.float64) if ctx_dim else None
     sd = {k: v.detach().double() for k, v in net.state_dict().items()}

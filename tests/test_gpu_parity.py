@@ -887,6 +887,39 @@ def test_graphed_flow_replays_match_eager(hip, kind):
 
 
 # ---------------------------------------------------------------- fused RQS layer, d_id = d_t = 16 family
+@pytest.mark.parametrize("d,blocks,ctx_dim", [(64, 1, 16), (64, 3, 16), (32, 3, 0), (64, 1, 0)])
+def test_fused_rqs_layer_one_and_three_blocks(hip, d, blocks, ctx_dim):
+    """The fp16 split-half one-kernel layer with 1 and 3 residual blocks (the exact fp32 matrix path covers
+    two-block layers only and is not eligible here)."""
+    from vcnf_amd import fused
+    torch.manual_seed(7 * d + blocks)
+    lay = nf.flows.CoupledRationalQuadraticSpline(d, blocks, 128, 8, num_context_channels=ctx_dim or None)
+    with torch.no_grad():
+        for n, p in lay.named_parameters():
+            if "final_layer" in n or "unconditional" in n:
+                p.normal_(0, 0.5)
+    sd = {k: v.detach().clone() for k, v in lay.state_dict().items()}
+    lay = lay.cuda()
+    b = 515
+    x = 1.5 * torch.randn(b, d)
+    ctx = torch.randn(b, 16) if ctx_dim else None
+    cg = dev(ctx) if ctx_dim else None
+    assert fused.eligible(lay.prqct, cg)
+    lay.prqct.fused_precision = "fp32"
+    assert not fused.eligible(lay.prqct, cg)
+    lay.prqct.fused_precision = "fp16x3"
+    o32 = oracle_rqs_coupling(sd, "prqct.", 8, 3.0, 128)
+    o64 = oracle_rqs_coupling({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, "prqct.", 8, 3.0, 128)
+    with torch.no_grad():
+        for dirn in ("forward", "inverse"):
+            z, ld = getattr(lay, dirn)(dev(x), cg)
+            w32 = getattr(o32, dirn)(x, ctx)
+            w64 = getattr(o64, dirn)(x.double(), ctx.double() if ctx_dim else None)
+            parity(z, w32[0], w64[0], what="z " + dirn)
+            parity(ld, w32[1], w64[1], rtol=1e-5, atol=2e-5, what="ld " + dirn)
+    nf.check_discriminant()
+
+
 @pytest.mark.parametrize("ctx_dim", [0, 16])
 @pytest.mark.parametrize("precision", ["fp16x3", "fp32"])
 def test_fused_rqs_layer_d32_family(hip, ctx_dim, precision):
@@ -956,7 +989,7 @@ def test_permute_folded_into_fused_affine_layer(hip):
 
 # ---------------------------------------------------------------- last layer + splines in one kernel (any d_t)
 @pytest.mark.parametrize("d,k,blocks,ctx_dim,batch", [
-    (64, 8, 3, 16, 1000),        # C3-like but 3 residual blocks: outside the one-kernel families
+    (48, 8, 3, 16, 1000),        # d_id = d_t = 24: outside the one-kernel families
     (1024, 16, 2, 0, 300),       # config C5's layer shape
     (42, 8, 1, 0, 77),           # d_t = 21: last feature group partly empty
     (10, 16, 2, 5, 4097)])

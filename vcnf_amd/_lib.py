@@ -58,7 +58,7 @@ PROTOTYPES = {
                                ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P], _INT),
     "vcnf_rqs_conditioner_input_f32": ([_P, _I64, _I32, _P, _I32, _P, _I32, _P, _P, _P,
                                         ctypes.POINTER(RqsCfg), _INT, _P, _P], _INT),
-    "vcnf_rqs_layer_fused_pack_floats": ([_I32, _I32, _I32], _I64),
+    "vcnf_rqs_layer_fused_pack_floats": ([_I32, _I32, _I32, _I32], _I64),
     "vcnf_rqs_layer_fused_supported": ([_I32, _I32, _I32, _I32, _I32, _I32, _I32], _INT),
     "vcnf_rqs_layer_fused_f32": ([_P, _P, _P, _P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _I64,
                                   _P, _P, _P, ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P], _INT),

@@ -5,10 +5,16 @@ resulting .so travels to the GPU box with the repository snapshot.
 """
 import os
 import subprocess
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libvcnf_hip.so")
-SOURCES = ["rqs_kernels.hip", "affine_kernels.hip", "fused_layer.hip", "fused_layer_v2.hip", "fused_layer_v3.hip", "fused_layer_v4.hip", "fused_affine.hip", "fused_final.hip", "rqs_backward.hip"]
+SOURCES = ["rqs_kernels.hip", "affine_kernels.hip", "fused_layer.hip", "fused_layer_v2.hip", "fused_layer_v3.hip",
+           "fused_layer_v4.hip", "fused_affine.hip", "fused_final.hip", "rqs_backward.hip"]
+# (source, extra flags, object name): fused_layer_v4.hip is compiled once per number of residual blocks
+UNITS = [(s, [], os.path.splitext(s)[0]) for s in SOURCES if s != "fused_layer_v4.hip"] + \
+        [("fused_layer_v4.hip", ["-DVCNF_V4_NBLK=%d" % n], "fused_layer_v4_b%d" % n) for n in (2, 3, 1)]
 HEADERS = ["rqs_math.hpp", "fused_common.hpp", os.path.join("..", "..", "include", "vcnf_hip.h")]
 
 
@@ -20,15 +26,28 @@ def stale():
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source into one shared library.  Returns its path."""
+    """Compile every HIP source (one hipcc process per file, in parallel) and link them into one
+    shared library.  Returns its path.  The object files live in a temporary directory."""
     if not force and not stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB] + SOURCES
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, cwd=CSRC, check=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    jobs = max(1, min(len(UNITS), int(os.environ.get("VCNF_BUILD_JOBS", os.cpu_count() or 1))))
+    with tempfile.TemporaryDirectory(prefix="vcnf_obj_") as tmp:
+        def compile_one(unit):
+            src, extra, name = unit
+            obj = os.path.join(tmp, name + ".o")
+            cmd = [hipcc] + flags + extra + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, cwd=CSRC, check=True)
+            return obj
+        with ThreadPoolExecutor(max_workers=jobs) as pool:
+            objs = list(pool.map(compile_one, sorted(UNITS, key=lambda u: not u[0].startswith("fused_layer"))))
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(link), flush=True)
+        subprocess.run(link, cwd=CSRC, check=True)
     return LIB
 
 

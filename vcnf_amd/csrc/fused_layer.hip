@@ -302,17 +302,28 @@ static int launch_fused(const FusedArgs& a, int inverse, hipStream_t st) {
 
 using namespace vcnf;
 
-// shape family: d_id = d_t in {16, 32}, context 0 or 16 (hidden 128, 2 residual blocks, 8 bins, linear tails)
-extern "C" int64_t vcnf_rqs_layer_fused_pack_floats(int32_t d_id, int32_t d_t, int32_t ctx_dim) {
+// shape family: d_id = d_t in {16, 32}, context 0 or 16, 1-3 residual blocks (hidden 128, 8 bins, linear
+// tails).  Two blocks run on both matrix paths; one and three blocks on the fp16 split-half path only.
+template <int NBLK>
+static int64_t pack_total(int d_id, int ctx_dim) {
+  if (d_id == 32) return ctx_dim == 16 ? PackLayout<32, 32, 16, 128, NBLK, 8>::TOTAL : PackLayout<32, 32, 0, 128, NBLK, 8>::TOTAL;
+  return ctx_dim == 16 ? PackLayout<16, 16, 16, 128, NBLK, 8>::TOTAL : PackLayout<16, 16, 0, 128, NBLK, 8>::TOTAL;
+}
+
+extern "C" int64_t vcnf_rqs_layer_fused_pack_floats(int32_t d_id, int32_t d_t, int32_t ctx_dim, int32_t num_blocks) {
   if (d_id != d_t || (d_id != 16 && d_id != 32) || (ctx_dim != 0 && ctx_dim != 16)) return 0;
-  if (d_id == 32) return ctx_dim == 16 ? PackLayout<32, 32, 16, 128, 2, 8>::TOTAL : PackLayout<32, 32, 0, 128, 2, 8>::TOTAL;
-  return ctx_dim == 16 ? PackLayout<16, 16, 16, 128, 2, 8>::TOTAL : PackLayout<16, 16, 0, 128, 2, 8>::TOTAL;
+  switch (num_blocks) {
+    case 1: return pack_total<1>(d_id, ctx_dim);
+    case 2: return pack_total<2>(d_id, ctx_dim);
+    case 3: return pack_total<3>(d_id, ctx_dim);
+    default: return 0;
+  }
 }
 
 extern "C" int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t ctx_dim, int32_t hidden,
                                               int32_t num_blocks, int32_t num_bins, int32_t tails) {
-  if (tails != VCNF_TAILS_LINEAR || num_bins != 8 || hidden != 128 || num_blocks != 2) return 0;
-  return vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim) > 0 ? 1 : 0;
+  if (tails != VCNF_TAILS_LINEAR || num_bins != 8 || hidden != 128) return 0;
+  return vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim, num_blocks) > 0 ? 1 : 0;
 }
 
 // VCNF_FUSED_KERNEL=v2|v3 selects an earlier work split of the fp16 split-half kernel (A/B timing);
@@ -326,9 +337,14 @@ static int fused_version() {
   return v;
 }
 
-static int launch_f16x3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
-  const int v = d_id == 32 ? fused_version() : 4;      // the earlier work splits exist for d_id = 32 only
-  if (v == 4) return launch_fused_v4(a, d_id, ctx_dim, inverse, st);
+static int launch_f16x3(const FusedArgs& a, int d_id, int ctx_dim, int num_blocks, int inverse, hipStream_t st) {
+  // the earlier work splits exist for d_id = 32 with two blocks only
+  const int v = (d_id == 32 && num_blocks == 2) ? fused_version() : 4;
+  if (v == 4) {
+    if (num_blocks == 1) return launch_fused_v4_b1(a, d_id, ctx_dim, inverse, st);
+    if (num_blocks == 2) return launch_fused_v4_b2(a, d_id, ctx_dim, inverse, st);
+    return launch_fused_v4_b3(a, d_id, ctx_dim, inverse, st);
+  }
   if (ctx_dim == 16) return v == 2 ? launch_fused_v2_c16(a, inverse, st) : launch_fused_v3_c16(a, inverse, st);
   return v == 2 ? launch_fused_v2_c0(a, inverse, st) : launch_fused_v3_c0(a, inverse, st);
 }
@@ -372,8 +388,9 @@ extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, fl
   a.c.wh_scale = cfg->wh_scale;
   a.c.edge_logit = (float)log(exp(1.0 - (double)cfg->min_derivative) - 1.0);
   hipStream_t st = (hipStream_t)stream;
-  if (wpack_floats != vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim)) return VCNF_ERR_SHAPE;
-  if (precision == VCNF_PREC_F16X3) return launch_f16x3(a, d_id, ctx_dim, inverse, st);
+  if (wpack_floats != vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim, num_blocks)) return VCNF_ERR_SHAPE;
+  if (precision == VCNF_PREC_F16X3) return launch_f16x3(a, d_id, ctx_dim, num_blocks, inverse, st);
+  if (num_blocks != 2) return VCNF_ERR_UNSUPPORTED;      // exact fp32 matrix path: two-block layers only
   if (d_id == 32)
     return ctx_dim == 16 ? launch_fused<32, 32, 16, 128, 2, 8, 2>(a, inverse, st)
                          : launch_fused<32, 32, 0, 128, 2, 8, 2>(a, inverse, st);

@@ -526,12 +526,34 @@ static int launch_v4(const FusedArgs& a, int inverse, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }
 
-// Shape family of the fused fp16 split-half kernel: (d_id, d_t, ctx) with H = 128, 2 blocks, 8 bins.
-int launch_fused_v4(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+// Shape family of the fused fp16 split-half kernel: (d_id = d_t, ctx, residual blocks) with H = 128, 8 bins.
+template <int NBLK>
+static int launch_v4_family(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
   if (d_id == 32) {
-    return ctx_dim == 16 ? launch_v4<32, 32, 16, 128, 2, 8>(a, inverse, st) : launch_v4<32, 32, 0, 128, 2, 8>(a, inverse, st);
+    return ctx_dim == 16 ? launch_v4<32, 32, 16, 128, NBLK, 8>(a, inverse, st)
+                         : launch_v4<32, 32, 0, 128, NBLK, 8>(a, inverse, st);
   }
-  return ctx_dim == 16 ? launch_v4<16, 16, 16, 128, 2, 8>(a, inverse, st) : launch_v4<16, 16, 0, 128, 2, 8>(a, inverse, st);
+  return ctx_dim == 16 ? launch_v4<16, 16, 16, 128, NBLK, 8>(a, inverse, st)
+                       : launch_v4<16, 16, 0, 128, NBLK, 8>(a, inverse, st);
 }
+
+// One translation unit per number of residual blocks (-DVCNF_V4_NBLK=1|2|3; each takes ~45 s to
+// compile, build.py runs them in parallel); fused_layer.hip dispatches to launch_fused_v4_b<N>.
+#ifndef VCNF_V4_NBLK
+#define VCNF_V4_NBLK 2
+#endif
+#if VCNF_V4_NBLK == 1
+int launch_fused_v4_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+  return launch_v4_family<1>(a, d_id, ctx_dim, inverse, st);
+}
+#elif VCNF_V4_NBLK == 2
+int launch_fused_v4_b2(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+  return launch_v4_family<2>(a, d_id, ctx_dim, inverse, st);
+}
+#else
+int launch_fused_v4_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+  return launch_v4_family<3>(a, d_id, ctx_dim, inverse, st);
+}
+#endif
 
 }  // namespace vcnf

@@ -160,6 +160,8 @@ def eligible(coupling, context):
         return False
     if context is not None and (context.dim() != 2 or context.shape[1] != ctx_dim):
         return False
+    if len(blocks) != 2 and precision_of(coupling) != PREC_F16X3:
+        return False                                    # the exact fp32 matrix path covers two-block layers only
     return bool(_lib.lib().vcnf_rqs_layer_fused_supported(
         coupling.num_identity_features, coupling.num_transform_features, ctx_dim,
         net.hidden_features, len(blocks), coupling.num_bins, _lib.TAILS_LINEAR))
