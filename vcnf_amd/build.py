@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libvcnf_hip.so")
 SOURCES = ["rqs_kernels.hip", "affine_kernels.hip", "fused_layer.hip", "fused_layer_v2.hip", "fused_layer_v3.hip",
-           "fused_layer_v4.hip", "fused_affine.hip", "fused_final.hip", "rqs_backward.hip"]
+           "fused_layer_v4.hip", "fused_layer_v5.hip", "fused_affine.hip", "fused_final.hip", "rqs_backward.hip"]
 # (source, extra flags, object name): fused_layer_v4.hip is compiled once per number of residual blocks
 UNITS = [(s, [], os.path.splitext(s)[0]) for s in SOURCES if s != "fused_layer_v4.hip"] + \
         [("fused_layer_v4.hip", ["-DVCNF_V4_NBLK=%d" % n], "fused_layer_v4_b%d" % n) for n in (2, 3, 1)]
@@ -33,7 +33,12 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
     jobs = max(1, min(len(UNITS), int(os.environ.get("VCNF_BUILD_JOBS", os.cpu_count() or 1))))
+    keep = os.environ.get("VCNF_OBJ_DIR")            # keep the object files (variant links of one unit)
+    if keep:
+        os.makedirs(keep, exist_ok=True)
     with tempfile.TemporaryDirectory(prefix="vcnf_obj_") as tmp:
+        if keep:
+            tmp = keep
         def compile_one(unit):
             src, extra, name = unit
             obj = os.path.join(tmp, name + ".o")

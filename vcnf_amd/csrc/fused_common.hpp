@@ -118,5 +118,7 @@ int launch_fused_v3_c0(const FusedArgs& a, int inverse, hipStream_t st);
 int launch_fused_v4_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
 int launch_fused_v4_b2(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
 int launch_fused_v4_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
+// defined in fused_layer_v5.hip
+int launch_fused_v5_c16(const FusedArgs& a, int inverse, hipStream_t st);
 
 }  // namespace vcnf

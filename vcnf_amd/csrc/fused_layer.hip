@@ -326,20 +326,22 @@ extern "C" int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t
   return vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim, num_blocks) > 0 ? 1 : 0;
 }
 
-// VCNF_FUSED_KERNEL=v2|v3 selects an earlier work split of the fp16 split-half kernel (A/B timing);
+// VCNF_FUSED_KERNEL=v2|v3 selects an earlier work split of the fp16 split-half kernel (A/B timing),
+// v5 the experimental activation-stationary one (fused_layer_v5.hip; context 16, two blocks only);
 // default: v4 (fused_layer_v4.hip).
 static int fused_version() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("VCNF_FUSED_KERNEL");
-    v = (e && e[0] == 'v' && e[1] >= '2' && e[1] <= '4') ? e[1] - '0' : 4;
-  }
-  return v;
+  // read on every call (one getenv per launch): tests switch kernels inside one process
+  const char* e = getenv("VCNF_FUSED_KERNEL");
+  return (e && e[0] == 'v' && e[1] >= '2' && e[1] <= '5') ? e[1] - '0' : 4;
 }
 
 static int launch_f16x3(const FusedArgs& a, int d_id, int ctx_dim, int num_blocks, int inverse, hipStream_t st) {
   // the earlier work splits exist for d_id = 32 with two blocks only
-  const int v = (d_id == 32 && num_blocks == 2) ? fused_version() : 4;
+  int v = (d_id == 32 && num_blocks == 2) ? fused_version() : 4;
+  if (v == 5) {
+    if (ctx_dim == 16) return launch_fused_v5_c16(a, inverse, st);
+    v = 4;
+  }
   if (v == 4) {
     if (num_blocks == 1) return launch_fused_v4_b1(a, d_id, ctx_dim, inverse, st);
     if (num_blocks == 2) return launch_fused_v4_b2(a, d_id, ctx_dim, inverse, st);

@@ -126,25 +126,41 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
 
     // ---- identity half through the unconditional spline: 4 lanes per sample, each lane a run
     // of DI/4 features; per-sample log|det| of this half parked in LDS.
-#define VCNF_IDENTITY_ROW(ROW)                                                            \
+    // (branch-free per feature: points outside the interval are evaluated at the left end and selected
+    // to the identity afterwards, so the table reads of UNR features are in flight together)
+#define VCNF_IDENTITY_ROW(ROW, UNR)                                                       \
   {                                                                                       \
     const int mi = (ROW);                                                                 \
     float lsum = 0.f;                                                                     \
-    _Pragma("unroll") for (int k = 0; k < DI / 4; ++k) {                                  \
-      const int f = (tid & 3) * (DI / 4) + k;                                             \
-      float* px = xt + mi * XS + idi[f];                                                  \
-      const float xv = *px;                                                               \
-      float yv = xv, lad = 0.f;                                                           \
-      if (shared) rqs_point_table<INV, K>(xv, tab + f * TABW, c, yv, lad, bad);           \
-      *px = yv;                                                                           \
-      lsum += lad;                                                                        \
+    if (shared) {                                                                         \
+      _Pragma("unroll") for (int k0 = 0; k0 < DI / 4; k0 += (UNR)) {                      \
+        float yv[UNR], lad[UNR], xv[UNR];                                                 \
+        bool in_[UNR];                                                                    \
+        float* px[UNR];                                                                   \
+        _Pragma("unroll") for (int k = 0; k < (UNR); ++k) {                               \
+          const int f = (tid & 3) * (DI / 4) + k0 + k;                                    \
+          px[k] = xt + mi * XS + idi[f];                                                  \
+          xv[k] = *px[k];                                                                 \
+          in_[k] = (xv[k] >= c.lo_x) && (xv[k] <= c.hi_x);                                \
+        }                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < (UNR); ++k) {                               \
+          const int f = (tid & 3) * (DI / 4) + k0 + k;                                    \
+          bool bad1 = false;                                                              \
+          rqs_point_table_inside<INV, K>(in_[k] ? xv[k] : c.lo_x, tab + f * TABW, yv[k], lad[k], bad1); \
+          bad = bad || bad1;                                                              \
+        }                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < (UNR); ++k) {                               \
+          *px[k] = in_[k] ? yv[k] : xv[k];                                                \
+          lsum += in_[k] ? lad[k] : 0.f;                                                  \
+        }                                                                                 \
+      }                                                                                   \
     }                                                                                     \
     lsum += __shfl_xor(lsum, 1, 64);                                                      \
     lsum += __shfl_xor(lsum, 2, 64);                                                      \
     if ((tid & 3) == 0) ldt[mi] = lsum;                                                   \
   }
     if (INV) {                               // the conditioner sees the transformed identity half
-      VCNF_IDENTITY_ROW(tid >> 2)
+      VCNF_IDENTITY_ROW(tid >> 2, DI / 4)
       __syncthreads();
     }
     if (ch == 1) __syncthreads();            // ---- group B now runs one step behind group A
@@ -218,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
     // (density direction), relu(h) published
     VCNF_LOAD_HIDDEN(L::BLK0 + L::WA, L::BLK0 + L::BA)
     if (!INV) {
-      VCNF_IDENTITY_ROW(64 * ch + ((tid & 255) >> 2))
+      VCNF_IDENTITY_ROW(64 * ch + ((tid & 255) >> 2), 4)
     }
     VCNF_PUBLISH(h, true)
     __syncthreads();

@@ -152,6 +152,77 @@ __device__ __forceinline__ void rqs_select(float x, const P& p, const RqsConst& 
   sel.d1 = c.min_d + softplus_f(sel.d1);
 }
 
+// rqs_select<K, INV> cut into stages with the same arithmetic in the same order, so that a kernel
+// can place other work (matrix instructions) between the stages: maxima + exponentials of bins
+// [k0, k1), normalisers, knots + bin search over [k0, k1), derivatives.
+template <int K, bool INV>
+struct RqsStaged {
+  float ew[K], eh[K];
+  float mw, mh, sw, sh, gw, gh, cw, ch, xl, yl, dl;
+  RqsBin sel;
+  template <class P>
+  __device__ __forceinline__ void maxima(const P& p) {
+    mw = -INFINITY;
+    mh = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      mw = fmaxf(mw, p.w(k));
+      mh = fmaxf(mh, p.h(k));
+    }
+    sw = 0.f;
+    sh = 0.f;
+  }
+  // bins [k0, k1): the bounds are constants at every (inlined, unrolled) call site
+  template <class P>
+  __device__ __forceinline__ void exps(const P& p, float sc2, int k0, int k1) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (k >= k0 && k < k1) {
+        ew[k] = hw_exp2((p.w(k) - mw) * sc2);
+        eh[k] = hw_exp2((p.h(k) - mh) * sc2);
+        sw += ew[k];
+        sh += eh[k];
+      }
+    }
+  }
+  template <class P>
+  __device__ __forceinline__ void normalise(const P& p, const RqsConst& c) {
+    gw = div_nr(c.free_w, sw);
+    gh = div_nr(c.free_h, sh);
+    cw = 0.f;
+    ch = 0.f;
+    xl = c.lo_x;
+    yl = c.lo_y;
+    dl = p.d(0);
+    sel.xl = xl; sel.yl = yl; sel.w = 1.f; sel.h = 1.f; sel.d0 = dl; sel.d1 = dl;
+  }
+  template <class P>
+  __device__ __forceinline__ void knots(float x, const P& p, const RqsConst& c, int k0, int k1) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (k < k0 || k >= k1) continue;
+      cw += fmaf(ew[k], gw, c.min_w);
+      ch += fmaf(eh[k], gh, c.min_h);
+      const float xr = (k == K - 1) ? c.hi_x : fmaf(c.span_x, cw, c.lo_x);
+      const float yr = (k == K - 1) ? c.hi_y : fmaf(c.span_y, ch, c.lo_y);
+      const float dr = p.d(k + 1);
+      const bool take = (k == 0) || (INV ? (x >= yl) : (x >= xl));
+      // plain selects (no branch: the stages share scheduling regions with matrix instructions)
+      sel.xl = take ? xl : sel.xl;
+      sel.w = take ? xr - xl : sel.w;
+      sel.yl = take ? yl : sel.yl;
+      sel.h = take ? yr - yl : sel.h;
+      sel.d0 = take ? dl : sel.d0;
+      sel.d1 = take ? dr : sel.d1;
+      xl = xr; yl = yr; dl = dr;
+    }
+  }
+  __device__ __forceinline__ void derivatives(const RqsConst& c) {
+    sel.d0 = c.min_d + softplus_f(sel.d0);
+    sel.d1 = c.min_d + softplus_f(sel.d1);
+  }
+};
+
 // Full evaluation with tails handling (splines.py:30-43: outside -> identity, 0).
 template <int KT, bool INV, class P>
 __device__ __forceinline__ void rqs_point(float x, const P& p, const RqsConst& c,
@@ -269,6 +340,27 @@ __device__ __forceinline__ void rqs_point_table(float x, const float* tab, const
   } else {
     for (int k = 1; k < K; ++k) bin += (x >= key[k]) ? 1 : 0;
   }
+  RqsBin b;
+  b.xl = xk[bin];
+  b.w = xk[bin + 1] - b.xl;
+  b.yl = yk[bin];
+  b.h = yk[bin + 1] - b.yl;
+  b.d0 = dk[bin];
+  b.d1 = dk[bin + 1];
+  rqs_bin_eval<INV>(x, b, y, lad, bad);
+}
+
+// rqs_point_table for a point already known to lie inside the interval (no tails branch): the caller
+// selects the identity for outside points afterwards.  KT > 0 only.
+template <bool INV, int KT>
+__device__ __forceinline__ void rqs_point_table_inside(float x, const float* tab, float& y, float& lad, bool& bad) {
+  const float* xk = tab;
+  const float* yk = tab + (KT + 1);
+  const float* dk = tab + 2 * (KT + 1);
+  const float* key = INV ? yk : xk;
+  int bin = 0;
+#pragma unroll
+  for (int k = 1; k < KT; ++k) bin += (x >= key[k]) ? 1 : 0;
   RqsBin b;
   b.xl = xk[bin];
   b.w = xk[bin + 1] - b.xl;
