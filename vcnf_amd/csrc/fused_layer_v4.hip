@@ -100,25 +100,44 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
 
   const long long ntiles = (a.B + kTile - 1) / kTile;
   bool bad = false;
+  // rows of the next tile travel in registers: bounds-checked buffer loads (rows past the batch read 0)
+  float4 xpre[kTile * (D / 4) / kBlock], cpre[C > 0 ? (kTile * (C / 4) + kBlock - 1) / kBlock : 1];
+  static_assert(kTile * (D / 4) % kBlock == 0 && (C == 0 || kTile * (C / 4) == kBlock), "rows per thread");
+#define VCNF_PREFETCH_ROWS(TILE)                                                          \
+  {                                                                                       \
+    const long long pb0 = min((TILE) * kTile, a.B);                                       \
+    const long long left = (a.B - pb0) * (D * 4);                                         \
+    const __amdgpu_buffer_rsrc_t xr_ = __builtin_amdgcn_make_buffer_rsrc(                 \
+        const_cast<float*>(a.x) + pb0 * D, 0, (int)min(left, (long long)(kTile * D * 4)), 0x00020000); \
+    _Pragma("unroll") for (int k = 0; k < kTile * (D / 4) / kBlock; ++k)                  \
+      xpre[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr_, (tid + kBlock * k) * 16, 0, 0)); \
+    if (C > 0) {                                                                          \
+      const long long leftc = (a.B - pb0) * (C * 4);                                      \
+      const __amdgpu_buffer_rsrc_t cr_ = __builtin_amdgcn_make_buffer_rsrc(               \
+          const_cast<float*>(a.ctx) + pb0 * C, 0, (int)min(leftc, (long long)(kTile * C * 4)), 0x00020000); \
+      cpre[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(cr_, tid * 16, 0, 0)); \
+    }                                                                                     \
+  }
+  VCNF_PREFETCH_ROWS((long long)blockIdx.x)
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long b0 = tile * kTile;
     const int rows = (int)min((long long)kTile, a.B - b0);
     __syncthreads();
-    {   // ---- stage x and context rows
+    {   // ---- x and context rows: requested during the previous tile's last vector step (or before the loop)
       constexpr int D4 = D / 4;
-      const float4* sx = reinterpret_cast<const float4*>(a.x) + b0 * D4;
-      for (int i = tid; i < kTile * D4; i += kBlock) {
+#pragma unroll
+      for (int k = 0; k < kTile * D4 / kBlock; ++k) {
+        const int i = tid + kBlock * k;
         const int r = i / D4, o = i - r * D4;
-        const float4 v = r < rows ? sx[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(xt + r * XS + 4 * o) = v;
+        *reinterpret_cast<float4*>(xt + r * XS + 4 * o) = xpre[k];
       }
       if (C > 0) {
         constexpr int C4 = (C > 0 ? C : 4) / 4;
-        const float4* sc = reinterpret_cast<const float4*>(a.ctx) + b0 * C4;
-        for (int i = tid; i < kTile * C4; i += kBlock) {
+#pragma unroll
+        for (int k = 0; k < kTile * C4 / kBlock; ++k) {
+          const int i = tid + kBlock * k;
           const int r = i / C4, o = i - r * C4;
-          const float4 v = r < rows ? sc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(ct + r * CS + 4 * o) = v;
+          *reinterpret_cast<float4*>(ct + r * CS + 4 * o) = cpre[k];
         }
       }
     }
@@ -437,6 +456,9 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
         // ---- step V: two spline evaluations per lane; the group's next window and bias travel meanwhile
         const bool more = rnd + 1 < NR;
         floatx4 stg[NSTG / 2];
+        if (!more) {                           // last vector step of the tile: the next tile's rows are requested
+          VCNF_PREFETCH_ROWS(tile + gridDim.x)
+        }
         if (more && VCNF_ABL != 2) {
           VCNF_STAGE_LOAD(stg, 0, g + 2)
         }
@@ -476,6 +498,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
       __syncthreads();
     }
     if (ch == 0) __syncthreads();            // ---- groups re-aligned: every spline of the tile is done
+#undef VCNF_PREFETCH_ROWS
 #undef VCNF_STAGE_LOAD
 #undef VCNF_STAGE_STORE
 #undef VCNF_LOAD_BIAS
