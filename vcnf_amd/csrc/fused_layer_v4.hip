@@ -33,6 +33,16 @@
 #ifndef VCNF_ABL
 #define VCNF_ABL 0
 #endif
+// -DVCNF_TIME=1: s_memtime stamps at every barrier; wave 0 of workgroup 0 leaves the per-phase sums in
+// the first output row (timing builds only, read by profiles/tools/v4_phase_timing.py)
+#ifndef VCNF_TIME
+#define VCNF_TIME 0
+#endif
+#if VCNF_TIME
+#define VCNF_T(I) { const long long t_ = clock64(); tacc[I] += t_ - tlast; tlast = t_; }
+#else
+#define VCNF_T(I)
+#endif
 
 namespace vcnf {
 
@@ -100,6 +110,10 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
 
   const long long ntiles = (a.B + kTile - 1) / kTile;
   bool bad = false;
+#if VCNF_TIME
+  long long tacc[16], tlast = clock64();
+  for (int i = 0; i < 16; ++i) tacc[i] = 0;
+#endif
   // rows of the next tile travel in registers: bounds-checked buffer loads (rows past the batch read 0)
   float4 xpre[kTile * (D / 4) / kBlock], cpre[C > 0 ? (kTile * (C / 4) + kBlock - 1) / kBlock : 1];
   static_assert(kTile * (D / 4) % kBlock == 0 && (C == 0 || kTile * (C / 4) == kBlock), "rows per thread");
@@ -122,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long b0 = tile * kTile;
     const int rows = (int)min((long long)kTile, a.B - b0);
-    __syncthreads();
+    { VCNF_T(0) __syncthreads(); VCNF_T(15) }
     {   // ---- x and context rows: requested during the previous tile's last vector step (or before the loop)
       constexpr int D4 = D / 4;
 #pragma unroll
@@ -141,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
         }
       }
     }
-    __syncthreads();
+    { VCNF_T(1) __syncthreads(); VCNF_T(15) }
 
     // ---- identity half through the unconditional spline: 4 lanes per sample, each lane a run
     // of DI/4 features; per-sample log|det| of this half parked in LDS.
@@ -180,9 +194,9 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
   }
     if (INV) {                               // the conditioner sees the transformed identity half
       VCNF_IDENTITY_ROW(tid >> 2, DI / 4)
-      __syncthreads();
+      { VCNF_T(2) __syncthreads(); VCNF_T(15) }
     }
-    if (ch == 1) __syncthreads();            // ---- group B now runs one step behind group A
+    if (ch == 1) { VCNF_T(14) __syncthreads(); VCNF_T(15) }            // ---- group B now runs one step behind group A
 
     // stationary weights of a hidden->hidden layer for this wave's two row blocks
     half8 ahi[2][NS32], alo[2][NS32];
@@ -231,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
         h[1][j] = acc[1];
       }
     }
-    __syncthreads();                         // ---- end of step M0
+    { VCNF_T(3) __syncthreads(); VCNF_T(15) }                         // ---- end of step M0
     // publish: the wave's two row blocks are the two 8-byte halves of one operand fragment
 #define VCNF_PUBLISH(SRC, RELU)                                                           \
   _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
       VCNF_IDENTITY_ROW(64 * ch + ((tid & 255) >> 2), 4)
     }
     VCNF_PUBLISH(h, true)
-    __syncthreads();
+    { VCNF_T(4) __syncthreads(); VCNF_T(15) }
 #undef VCNF_IDENTITY_ROW
 
     // OUT[rb][j] = bias + W_slice(rb) * operand(column block 4 ch + j).  The operand fragments of
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
       floatx4 t[2][4];
       // ---- step M: first layer of the block                                          resnet.py:42-43
       VCNF_HIDDEN_COMPUTE(t)
-      __syncthreads();
+      { VCNF_T(5) __syncthreads(); VCNF_T(15) }
       // ---- step V: publish relu(t) (:46); second layer's and gate weights requested
       VCNF_LOAD_HIDDEN(base + L::WB, base + L::BB)
       floatx4 wc[2], bc[2];
@@ -320,10 +334,10 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
         }
       }
       VCNF_PUBLISH(t, true)
-      __syncthreads();
+      { VCNF_T(6) __syncthreads(); VCNF_T(15) }
       // ---- step M: second layer of the block                                         :48
       VCNF_HIDDEN_COMPUTE(t)
-      __syncthreads();
+      { VCNF_T(5) __syncthreads(); VCNF_T(15) }
       // ---- step V: GLU gate on the context (fp32), residual update, publish          :49-57
       if (blk + 1 < NBLK) {
         VCNF_LOAD_HIDDEN(base + L::BLK + L::WA, base + L::BLK + L::BA)
@@ -355,9 +369,9 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
       } else {
         VCNF_PUBLISH(h, false)               // the last layer takes h itself (resnet.py:105)
       }
-      __syncthreads();
+      { VCNF_T(7) __syncthreads(); VCNF_T(15) }
     }
-    if (ch == 0) __syncthreads();            // ---- groups re-aligned: all activations are published
+    if (ch == 0) { VCNF_T(14) __syncthreads(); VCNF_T(15) }            // ---- groups re-aligned: all activations are published
 #undef VCNF_HIDDEN_COMPUTE
 #undef VCNF_READ_B
 #undef VCNF_LOAD_HIDDEN
@@ -393,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
   _Pragma("unroll") for (int b = 0; b < P4; ++b)                                          \
     pa[0][b] = wload(wr, q * (16 * P4), 4 * (L::BF + (G) * 4 * (4 * P4) + 4 * b));      /* bf[g][q][4b..] */
     VCNF_LOAD_BIAS(ch)
-    __syncthreads();                         // every wave has its operand fragments: the window may be written
+    { VCNF_T(8) __syncthreads(); VCNF_T(15) }                         // every wave has its operand fragments: the window may be written
     {   // first feature group of each wave group
       floatx4 stg[NSTG / 2];
       VCNF_STAGE_LOAD(stg, 0, ch)
@@ -401,8 +415,8 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
       VCNF_STAGE_LOAD(stg, NSTG / 2, ch)
       VCNF_STAGE_STORE(stg, NSTG / 2)
     }
-    __syncthreads();
-    if (ch == 1) __syncthreads();            // ---- group B one step behind again
+    { VCNF_T(9) __syncthreads(); VCNF_T(15) }
+    if (ch == 1) { VCNF_T(14) __syncthreads(); VCNF_T(15) }            // ---- group B one step behind again
     for (int rnd = 0; rnd < (VCNF_ABL == 3 ? 0 : NR); ++rnd) {
       const int g = 2 * rnd + ch;
       {
@@ -451,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
         __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
 #undef VCNF_READ_W
       }
-      __syncthreads();
+      { VCNF_T(10) __syncthreads(); VCNF_T(15) }
       {
         // ---- step V: two spline evaluations per lane; the group's next window and bias travel meanwhile
         const bool more = rnd + 1 < NR;
@@ -495,9 +509,9 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
           }
         }
       }
-      __syncthreads();
+      { VCNF_T(11) __syncthreads(); VCNF_T(15) }
     }
-    if (ch == 0) __syncthreads();            // ---- groups re-aligned: every spline of the tile is done
+    if (ch == 0) { VCNF_T(14) __syncthreads(); VCNF_T(15) }            // ---- groups re-aligned: every spline of the tile is done
 #undef VCNF_PREFETCH_ROWS
 #undef VCNF_STAGE_LOAD
 #undef VCNF_STAGE_STORE
@@ -514,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
 #pragma unroll
       for (int j = 0; j < 2; ++j) ldt[(2 * rp + j) * 16 + m16] += ld_acc[j];
     }
-    __syncthreads();
+    { VCNF_T(12) __syncthreads(); VCNF_T(15) }
     if (ch == 0 && q == 0) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -534,6 +548,12 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
       }
     }
   }
+#if VCNF_TIME
+  VCNF_T(13)
+  if (blockIdx.x == 0 && tid == 0) {
+    for (int i = 0; i < 16; ++i) a.y[i] = (float)tacc[i];
+  }
+#endif
   if (INV && a.bad && bad) atomicAdd(a.bad, 1);
 }
 
