@@ -44,6 +44,13 @@ __device__ __forceinline__ floatx4 wload(__amdgpu_buffer_rsrc_t rsrc, int voff, 
   return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
 }
 
+// 16 bytes per lane straight from a buffer into LDS (buffer_load_dwordx4 ... lds): lane l lands at
+// lds_base + 16 l, lds_base wave-uniform; completion is counted by vmcnt like any other load.
+__device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rsrc, void* lds_base, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void wait_vector_memory() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0)
+
 // Packed weight buffer of one layer, in floats (host side: vcnf_amd/fused.py::pack_layer):
 //   W0 [NB][NS0/4][64][4] | b0 [H] | per block: WA [NB][NSH/4][64][4] | ba [H] |
 //   WB [NB][NSH/4][64][4] | bb [H] | (WC [NB][NSC/4][64][4] | bc [H] if C > 0) |

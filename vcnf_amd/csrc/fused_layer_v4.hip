@@ -402,6 +402,11 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
     DST[k] = wload(wr, stg_voff, 4 * (L::WF + ((G) * P4 * NS32 + 2 * ((K0) + k)) * 256));
 #define VCNF_STAGE_STORE(SRC, K0)                                                         \
   _Pragma("unroll") for (int k = 0; k < NSTG / 2; ++k) win[gtid + ((K0) + k) * 256] = __builtin_bit_cast(uint4, SRC[k]);
+    // the same fragments straight from global memory into the window (buffer_load ... lds: no registers,
+    // no LDS write instructions; the wave's 64 lanes land at consecutive 16-byte slots of a wave-uniform base)
+#define VCNF_STAGE_DMA(G)                                                                 \
+  _Pragma("unroll") for (int k = 0; k < NSTG; ++k)                                        \
+    dma16_to_lds(wr, win + (gtid & ~63) + k * 256, stg_voff, 4 * (L::WF + ((G) * P4 * NS32 + 2 * k) * 256));
     floatx4 pa[2][P4];
 #define VCNF_LOAD_BIAS(G)                                                                 \
   _Pragma("unroll") for (int b = 0; b < P4; ++b)                                          \
@@ -469,12 +474,11 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
       {
         // ---- step V: two spline evaluations per lane; the group's next window and bias travel meanwhile
         const bool more = rnd + 1 < NR;
-        floatx4 stg[NSTG / 2];
         if (!more) {                           // last vector step of the tile: the next tile's rows are requested
           VCNF_PREFETCH_ROWS(tile + gridDim.x)
         }
         if (more && VCNF_ABL != 2) {
-          VCNF_STAGE_LOAD(stg, 0, g + 2)
+          VCNF_STAGE_DMA(g + 2)
         }
         const int col = tfi[4 * g + q];
 #pragma unroll
@@ -498,23 +502,21 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
 #endif
           *px = yv;
           ld_acc[j] += lad;
-          if (more && VCNF_ABL != 2) {
-            if (j == 0) {
-              VCNF_LOAD_BIAS(g + 2)
-              VCNF_STAGE_STORE(stg, 0)
-              VCNF_STAGE_LOAD(stg, NSTG / 2, g + 2)
-            } else {
-              VCNF_STAGE_STORE(stg, NSTG / 2)
-            }
+          if (more && j == 0) {
+            VCNF_LOAD_BIAS(g + 2)
           }
         }
       }
+      // this wave's part of the window must have landed before the other waves of the group read it
+      // (vmcnt(0); the loads were requested a whole vector step ago)
+      if (rnd + 1 < NR && VCNF_ABL != 2) wait_vector_memory();
       { VCNF_T(11) __syncthreads(); VCNF_T(15) }
     }
     if (ch == 0) { VCNF_T(14) __syncthreads(); VCNF_T(15) }            // ---- groups re-aligned: every spline of the tile is done
 #undef VCNF_PREFETCH_ROWS
 #undef VCNF_STAGE_LOAD
 #undef VCNF_STAGE_STORE
+#undef VCNF_STAGE_DMA
 #undef VCNF_LOAD_BIAS
 
     // ---- per-sample log|det|: this wave covered one group parity of its samples; the partner
