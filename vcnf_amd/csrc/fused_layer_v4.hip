@@ -336,9 +336,27 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
       VCNF_PUBLISH(t, true)
       { VCNF_T(6) __syncthreads(); VCNF_T(15) }
       // ---- step M: second layer of the block                                         :48
+      // and the gate pre-activations (fp32 instruction): matrix work belongs in the matrix step, the
+      // vector step that follows is the longer one of its pair (profiles/r01_fused_v4_phase_cycles.md)
       VCNF_HIDDEN_COMPUTE(t)
+      floatx4 gate[2][4];
+      if (C > 0 && VCNF_ABL != 6) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float* cr = ct + ((4 * ch + j) * 16 + m16) * CS;
+          float cv[NSC > 0 ? NSC : 1];
+#pragma unroll
+          for (int s = 0; s < NSC; ++s) cv[s] = cr[4 * s + q];
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) {
+            gate[rb][j] = bc[rb];
+#pragma unroll
+            for (int s = 0; s < NSC; ++s) gate[rb][j] = mfma4(wc[rb][s], cv[s], gate[rb][j]);
+          }
+        }
+      }
       { VCNF_T(5) __syncthreads(); VCNF_T(15) }
-      // ---- step V: GLU gate on the context (fp32), residual update, publish          :49-57
+      // ---- step V: GLU gate (sigmoid of the pre-activations), residual update, publish :49-57
       if (blk + 1 < NBLK) {
         VCNF_LOAD_HIDDEN(base + L::BLK + L::WA, base + L::BLK + L::BA)
       }
@@ -347,13 +365,9 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
         for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float* cr = ct + ((4 * ch + j) * 16 + m16) * CS;
-            floatx4 gate = bc[rb];
-#pragma unroll
-            for (int s = 0; s < NSC; ++s) gate = mfma4(wc[rb][s], cr[4 * s + q], gate);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float sg = div_nr(1.f, 1.f + hw_exp2(-gate[r] * kLog2e));
+              const float sg = div_nr(1.f, 1.f + hw_exp2(-gate[rb][j][r] * kLog2e));
               h[rb][j][r] = fmaf(t[rb][j][r], sg, h[rb][j][r]);
             }
           }
