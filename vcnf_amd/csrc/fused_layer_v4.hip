@@ -438,6 +438,12 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
     if (ch == 1) { VCNF_T(14) __syncthreads(); VCNF_T(15) }            // ---- group B one step behind again
     for (int rnd = 0; rnd < (VCNF_ABL == 3 ? 0 : NR); ++rnd) {
       const int g = 2 * rnd + ch;
+      // the two elements this lane transforms in the vector step: read before the matrix step, so the
+      // vector step does not start with two dependent LDS round trips
+      const int col = tfi[4 * g + q];
+      float xin[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) xin[j] = xt[((2 * rp + j) * 16 + m16) * XS + col];
       {
         // ---- step M: 144 matrix instructions on the group's window, fragments read two steps ahead
         half8 wh[3], wl[3];
@@ -494,11 +500,10 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
         if (more && VCNF_ABL != 2) {
           VCNF_STAGE_DMA(g + 2)
         }
-        const int col = tfi[4 * g + q];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           float* px = xt + ((2 * rp + j) * 16 + m16) * XS + col;
-          const float xv = *px;
+          const float xv = xin[j];
           RegLogits<K, P4> p{pa[j], c.wh_scale, c.edge_logit};
           float yv, lad;
 #if VCNF_ABL == 1
