@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
     // (density direction), relu(h) published
     VCNF_LOAD_HIDDEN(L::BLK0 + L::WA, L::BLK0 + L::BA)
     if (!INV) {
-      VCNF_IDENTITY_ROW(64 * ch + ((tid & 255) >> 2), 4)
+      VCNF_IDENTITY_ROW(64 * ch + ((tid & 255) >> 2), DI / 4)
     }
     VCNF_PUBLISH(h, true)
     { VCNF_T(4) __syncthreads(); VCNF_T(15) }
