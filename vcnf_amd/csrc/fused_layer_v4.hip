@@ -192,10 +192,32 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
     lsum += __shfl_xor(lsum, 2, 64);                                                      \
     if ((tid & 3) == 0) ldt[mi] = lsum;                                                   \
   }
-    if (INV) {                               // the conditioner sees the transformed identity half
-      VCNF_IDENTITY_ROW(tid >> 2, DI / 4)
-      { VCNF_T(2) __syncthreads(); VCNF_T(15) }
+    // first-layer operands of this wave's four column blocks.  Direction whose conditioner sees the
+    // transformed identity half: read after that half went through its splines; other direction: read
+    // first (raw values), then the identity half is transformed in place - with all eight waves at once
+    // in both directions (inside the ping-pong sequence each group's share was on the critical path).
+    float bv[4][NS0];
+#define VCNF_READ_FIRST_OPERANDS()                                                        \
+  {                                                                                       \
+    int xcol[DI / 4];                                                                     \
+    _Pragma("unroll") for (int s = 0; s < DI / 4; ++s) xcol[s] = idi[4 * s + q];          \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                       \
+      const float* xr = xt + ((4 * ch + j) * 16 + m16) * XS;                              \
+      const float* cr = ct + ((4 * ch + j) * 16 + m16) * CS;                              \
+      _Pragma("unroll") for (int s = 0; s < NS0; ++s)                                     \
+        bv[j][s] = s < DI / 4 ? xr[xcol[s < DI / 4 ? s : 0]] : cr[4 * (s - DI / 4) + q];  \
+    }                                                                                     \
+  }
+    if (!INV) {
+      VCNF_READ_FIRST_OPERANDS()
+      { VCNF_T(2) __syncthreads(); VCNF_T(15) }            // every wave has its raw operands
     }
+    VCNF_IDENTITY_ROW(tid >> 2, DI / 4)
+    { VCNF_T(2) __syncthreads(); VCNF_T(15) }
+    if (INV) {
+      VCNF_READ_FIRST_OPERANDS()
+    }
+#undef VCNF_READ_FIRST_OPERANDS
     if (ch == 1) { VCNF_T(14) __syncthreads(); VCNF_T(15) }            // ---- group B now runs one step behind group A
 
     // stationary weights of a hidden->hidden layer for this wave's two row blocks
@@ -221,17 +243,6 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
 #pragma unroll
         for (int s4 = 0; s4 < NS0_4; ++s4) w0[rb][s4] = wload(wr, voff, 4 * (L::W0 + (nb * NS0_4 + s4) * 256));
         bias[rb] = wload(wr, qoff, 4 * (L::B0 + 16 * nb));
-      }
-      int xcol[DI / 4];
-#pragma unroll
-      for (int s = 0; s < DI / 4; ++s) xcol[s] = idi[4 * s + q];
-      float bv[4][NS0];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float* xr = xt + ((4 * ch + j) * 16 + m16) * XS;
-        const float* cr = ct + ((4 * ch + j) * 16 + m16) * CS;
-#pragma unroll
-        for (int s = 0; s < NS0; ++s) bv[j][s] = s < DI / 4 ? xr[xcol[s]] : cr[4 * (s - DI / 4) + q];
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -263,12 +274,8 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v4_kernel(const FusedA
     act_hi[at] = __builtin_bit_cast(uint4, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7)); \
     act_lo[at] = __builtin_bit_cast(uint4, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7)); \
   }
-    // ---- step V1: first hidden layer's weights requested, identity half of this group's samples
-    // (density direction), relu(h) published
+    // ---- step V1: first hidden layer's weights requested, relu(h) published
     VCNF_LOAD_HIDDEN(L::BLK0 + L::WA, L::BLK0 + L::BA)
-    if (!INV) {
-      VCNF_IDENTITY_ROW(64 * ch + ((tid & 255) >> 2), DI / 4)
-    }
     VCNF_PUBLISH(h, true)
     { VCNF_T(4) __syncthreads(); VCNF_T(15) }
 #undef VCNF_IDENTITY_ROW
