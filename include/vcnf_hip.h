@@ -199,7 +199,7 @@ int vcnf_rqs_conditioner_input_f32(const float* x, int64_t batch, int32_t featur
  * vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim, num_blocks) floats (0: shape not supported) holding the ResidualNet's nn.Linear
  * weights (nets/resnet.py:78-90) re-ordered into matrix-core fragments, in the order
  *   W0 | b0 | per block: WA | ba | WB | bb | (WC | bc if ctx_dim > 0) | WF | bf
- * (exact fragment order: vcnf_amd/fused.py::pack_layer, csrc/fused_layer.hip PackLayout). */
+ * (exact fragment order: vcnf_amd/fused.py::pack_layer, csrc/fused_common.hpp PackLayout / PackLayout6). */
 int64_t vcnf_rqs_layer_fused_pack_floats(int32_t d_id, int32_t d_t, int32_t ctx_dim, int32_t num_blocks);
 
 /* 1 if vcnf_rqs_layer_fused_f32 has a kernel for this layer shape, else 0. */
@@ -214,10 +214,16 @@ int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t ctx_dim, i
  * conditioner output never touches HBM.  context[B, ctx_dim] may be NULL when
  * ctx_dim = 0.  x, y, context must be 16-byte aligned.
  * precision: VCNF_PREC_F32 - every dense layer on v_mfma_f32_16x16x4_f32 (exact fp32
- * fma chains); VCNF_PREC_F16X3 - the hidden->hidden and last layers on the fp16 matrix
- * instruction with operands split into hi + lo*2^-11 halves (22 significant bits, 3
- * instructions per product; hidden activations must stay below 65504 in magnitude);
- * wpack must have been packed for the same precision. */
+ * fma chains); VCNF_PREC_F16X3 - every dense layer on v_mfma_f32_32x32x16_f16 with both
+ * operands split into hi + lo*2^-11 fp16 halves (22 significant bits, 3 instructions
+ * per product, fp32 accumulation).  The split clamps at +-65504: inputs, context and
+ * hidden activations beyond that are NOT represented; sat_count (device int32, may be
+ * NULL) is incremented by every workgroup that clamped a value, so the caller can
+ * detect it and re-run with VCNF_PREC_F32 (the reference is plain fp32,
+ * nets/resnet.py:92-106).  wpack must have been packed for the same precision; the
+ * F16X3 buffer has the 1/sqrt(hidden) logit scale (coupling.py:314-316) and the
+ * log2(e) factors of the softmax / softplus / sigmoid exponentials folded in
+ * (vcnf_amd/fused.py::pack_layer_h3), cfg->wh_scale must be the folded value. */
 int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, float* logdet,
                              int64_t batch, const int32_t* transform_idx, int32_t d_t,
                              const int32_t* identity_idx, int32_t d_id, int32_t ctx_dim,
@@ -225,7 +231,8 @@ int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, flo
                              const float* wpack, int64_t wpack_floats,
                              const float* shared_w, const float* shared_h, const float* shared_d,
                              const vcnf_rqs_cfg* cfg, int inverse,
-                             int ld_mode, float ld_sign, int32_t* bad_disc, void* stream);
+                             int ld_mode, float ld_sign, int32_t* bad_disc, int32_t* sat_count,
+                             void* stream);
 
 /* Affine coupling on z[B, C, inner] (inner = H*W, 1 for 2-D inputs).
  * Replaces AffineCoupling.forward / .inverse (flows/affine/coupling.py:113-142 /

@@ -102,3 +102,129 @@ def test_pack_layout_conditional():
 
 def test_pack_layout_unconditional():
     _check(0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# fp16 split-half kernel (csrc/fused_layer_v6.hip): v_mfma_f32_32x32x16_f16 dataflow as measured on gfx950
+# (profiles/r02_mfma_32x32x16_layout.txt): A lane l = row l % 32, k-slots (l / 32, 0..7); B lane l = column
+# l % 32, same slots; D register r of lane l = row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32.
+C32, KG = LANE & 31, LANE >> 5
+
+
+def mfma32(a, b, acc):
+    """a, b: [64, 8] per-lane operands; acc: [64, 16]."""
+    A = np.zeros((32, 16)); B = np.zeros((16, 32))
+    for i in range(8):
+        A[C32, 8 * KG + i] = a[:, i]
+        B[8 * KG + i, C32] = b[:, i]
+    Dm = A @ B
+    return acc + np.stack([Dm[8 * (r >> 2) + 4 * KG + (r & 3), C32] for r in range(16)], axis=1)
+
+
+def _halves(floats):
+    """float32 words of the packed buffer -> the fp16 values they carry (two per word)."""
+    return np.ascontiguousarray(floats.astype(np.float32)).view(np.float16).astype(np.float64)
+
+
+def run_emulated6(buf, x_id, ctx, wh_scale, DI=32, DT=32, C=16, H=128, NBLK=2, K=8):
+    """One 32-sample column block through the packed conditioner -> logits [32, DT, P] (scales undone)."""
+    P = 3 * K - 1
+    NB, NT0, NTH, NTC, NG = H // 32, (DI + C) // 16, H // 16, C // 16, DT // 4
+    pos = [0]
+
+    def take(n):
+        out = buf[pos[0]:pos[0] + n]
+        pos[0] += n
+        return out
+
+    def frags(nb_count, nt):
+        hl = _halves(take(nb_count * nt * 512)).reshape(nb_count, nt, 2, 64, 8)
+        return hl[:, :, 0] + hl[:, :, 1] / 2048.0
+
+    def bias16(n):
+        return take(n).astype(np.float64).reshape(n // 32, 2, 16)
+
+    def operand_in(vec, t):          # natural order: slot (kg, i) of k-step t = vec[:, 16 t + 8 kg + i]
+        return np.stack([vec[C32, 16 * t + 8 * KG + i] for i in range(8)], axis=1)
+
+    def operand_acc(accs, t, relu):  # k-step t = registers 8 hh .. 8 hh + 7 of row block t // 2
+        v = accs[t >> 1][:, 8 * (t & 1):8 * (t & 1) + 8]
+        return np.maximum(v, 0) if relu else v
+
+    def layer(w, b, nt, bop):
+        out = []
+        for nb in range(w.shape[0]):
+            acc = b[nb][KG]
+            for t in range(nt):
+                acc = mfma32(w[nb, t], bop(t), acc)
+            out.append(acc)
+        return out
+    xin = np.concatenate([x_id, ctx], axis=1)
+    w0 = frags(NB, NT0); b0 = bias16(H)
+    h = layer(w0, b0, NT0, lambda t: operand_in(xin, t))
+    for _ in range(NBLK):
+        wa = frags(NB, NTH); ba = bias16(H)
+        wb = frags(NB, NTH); bb = bias16(H)
+        if C:
+            wc = frags(NB, NTC); bc = bias16(H)
+        t1 = layer(wa, ba, NTH, lambda t: operand_acc(h, t, True))
+        t2 = layer(wb, bb, NTH, lambda t: operand_acc(t1, t, True))
+        if C:
+            gate = layer(wc, bc, NTC, lambda t: operand_in(ctx, t))
+            t2 = [a / (1 + np.exp2(-g)) for a, g in zip(t2, gate)]
+        h = [a + b for a, b in zip(h, t2)]
+    wf = frags(NG * 3, NTH).reshape(NG, 3, NTH, 64, 8)
+    bf = take(NG * 96).astype(np.float64).reshape(NG, 2, 48)
+    assert pos[0] == len(buf)
+    logits = np.zeros((32, DT, P))
+    log2e = 1.4426950408889634
+    for g in range(NG):
+        pa = []
+        for b in range(3):
+            acc = bf[g][KG][:, 16 * b:16 * b + 16]
+            for t in range(NTH):
+                acc = mfma32(wf[g, b, t], operand_acc(h, t, False), acc)
+            pa.append(acc)
+        for lane in range(64):
+            for v in range(48):
+                f2, tl = divmod(v, 24)
+                if tl < P:
+                    sc = wh_scale * log2e if tl < 2 * K else log2e
+                    logits[C32[lane], 4 * g + 2 * KG[lane] + f2, tl] = pa[v >> 4][lane, v & 15] / sc
+                else:
+                    assert pa[v >> 4][lane, v & 15] == 0.0            # padding row
+    return logits
+
+
+def _check6(ctx_dim, d=64):
+    torch.manual_seed(14 + ctx_dim + d)
+    m = nf.flows.CoupledRationalQuadraticSpline(d, 2, 128, 8, num_context_channels=ctx_dim or None)
+    net = m.prqct.transform_net
+    with torch.no_grad():
+        for p in net.parameters():
+            p.normal_(0, 0.3)
+    di = d // 2
+    wh_scale = 1.0 / np.sqrt(128.0)
+    buf = fused.pack_layer_h3(net, di, 23, wh_scale, 8).numpy()
+    assert len(buf) == nf.lib().vcnf_rqs_layer_fused_pack_floats(di, di, ctx_dim, 2)
+    x_id = torch.randn(32, di, dtype=torch.float64)
+    ctx = torch.randn(32, ctx_dim, dtype=torch.float64) if ctx_dim else None
+    sd = {k: v.detach().double() for k, v in net.state_dict().items()}
+    want = ON.residual_net(sd, "", x_id, ctx).reshape(32, di, 23).numpy()
+    got = run_emulated6(buf, x_id.numpy(), ctx.numpy() if ctx_dim else np.zeros((32, 0)), wh_scale,
+                        DI=di, DT=di, C=ctx_dim)
+    # weights carry 22 significant bits (hi + lo / 2048), activations are exact here
+    assert np.allclose(got, want, rtol=2e-5, atol=2e-5 * np.abs(want).max()), np.abs(got - want).max()
+
+
+def test_pack_layout_h3_conditional():
+    _check6(16)
+
+
+def test_pack_layout_h3_unconditional():
+    _check6(0)
+
+
+def test_pack_layout_h3_d32():
+    _check6(16, d=32)
+    _check6(0, d=32)

@@ -625,34 +625,6 @@ def test_fused_path_is_taken_and_matches_split_path(hip):
     assert not fz.eligible(other.prqct, None)
 
 
-@pytest.mark.parametrize("batch", [128, 4096 + 37])
-def test_fused_v5_work_split_matches_v4(hip, batch, monkeypatch):
-    """fused_layer_v5.hip (activation-stationary waves, experimental, opt-in through
-    VCNF_FUSED_KERNEL=v5) computes the same layer as the default v4 kernel: same packed
-    weights, same arithmetic up to the order of the bias addition."""
-    torch.manual_seed(23)
-    m = nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8, num_context_channels=16).cuda().eval()
-    with torch.no_grad():
-        for n, p in m.named_parameters():
-            if "unnormalized" in n:
-                p.normal_(0, 0.5)
-            elif "final_layer.weight" in n:
-                p.normal_(0, 1.0 / np.sqrt(128))
-    set_fused(m, "fp16x3")
-    x = 1.4 * torch.randn(batch, 64, device="cuda")      # some points in the linear tails
-    ctx = torch.randn(batch, 16, device="cuda")
-    with torch.no_grad():
-        for dirn in ("inverse", "forward"):
-            monkeypatch.setenv("VCNF_FUSED_KERNEL", "v4")
-            z4, l4 = getattr(m, dirn)(x, context=ctx)
-            monkeypatch.setenv("VCNF_FUSED_KERNEL", "v5")
-            z5, l5 = getattr(m, dirn)(x, context=ctx)
-            assert not torch.equal(z5, x)
-            assert_close(z5, z4.cpu(), rtol=1e-4, atol=1e-4, what="v5 %s z" % dirn)
-            assert_close(l5, l4.cpu(), rtol=1e-4, atol=2e-3, what="v5 %s ld" % dirn)
-    nf.check_discriminant()
-
-
 def test_fp16x3_saturates_instead_of_nan(hip):
     """Hidden activations beyond the fp16 range saturate at +-65504 in the split-half
     matrix path: outputs stay finite (they differ from the fp32 path there, documented)."""

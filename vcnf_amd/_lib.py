@@ -61,7 +61,7 @@ PROTOTYPES = {
     "vcnf_rqs_layer_fused_pack_floats": ([_I32, _I32, _I32, _I32], _I64),
     "vcnf_rqs_layer_fused_supported": ([_I32, _I32, _I32, _I32, _I32, _I32, _I32], _INT),
     "vcnf_rqs_layer_fused_f32": ([_P, _P, _P, _P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _I64,
-                                  _P, _P, _P, ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P], _INT),
+                                  _P, _P, _P, ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P, _P], _INT),
     "vcnf_affine_coupling_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _INT, _INT,
                                   _INT, _F32, _P], _INT),
     "vcnf_masked_affine_f32": ([_P, _P, _P, _P, _P, _P, _I64, _I32, _INT, _INT, _F32, _P], _INT),
@@ -176,22 +176,63 @@ _BAD = {}
 EVENT_SINK = None
 
 
+def device_index(device):
+    """Explicit index of a CUDA device: 'cuda' without an index means the CURRENT device (the counters below
+    are kept per device; a rank whose current device is not 0 must not read device 0's)."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise VcnfError("vcnf_amd runs on HIP devices only (got %s)" % dev)
+    return torch.cuda.current_device() if dev.index is None else dev.index
+
+
+def _counter(table, device):
+    key = device_index(device)
+    if key not in table:
+        table[key] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", key))
+    return table[key]
+
+
 def bad_discriminant_counter(device):
     """Device int32 that the inverse spline kernels bump when b^2-4ac < 0 (the
     reference asserts on the host, splines.py:164)."""
-    key = torch.device(device).index or 0
-    if key not in _BAD:
-        _BAD[key] = torch.zeros(1, dtype=torch.int32, device=device)
-    return _BAD[key]
+    return _counter(_BAD, device)
+
+
+_SAT = {}
+
+
+def saturation_counter(device):
+    """Device int32 that the fp16 split-half fused layer kernel bumps (once per workgroup) when an input, a
+    context value or a hidden activation was clamped at +-65504."""
+    return _counter(_SAT, device)
 
 
 def check_discriminant(device="cuda"):
     """Host check (synchronises): raises AssertionError like splines.py:164 if an
     inverse spline saw a negative discriminant since the last check."""
-    c = bad_discriminant_counter(torch.device(device))
+    c = bad_discriminant_counter(device)
     n = int(c.item())
     c.zero_()
     assert n == 0, "negative discriminant in %d workgroup(s) of an inverse RQ spline" % n
+
+
+def check_saturation(device="cuda", model=None):
+    """Host check (synchronises) of the fp16 split-half matrix path: number of workgroups that clamped a value
+    at the fp16 range since the last check (the reference is plain fp32 and does not clamp, nets/resnet.py:92-106).
+    With ``model`` given and a non-zero count every fused RQS coupling of the model is switched to the exact
+    fp32 matrix path (``fused_precision = 'fp32'``), so that re-running the evaluation gives reference results;
+    without a model a non-zero count raises VcnfError."""
+    c = saturation_counter(device)
+    n = int(c.item())
+    c.zero_()
+    if n and model is None:
+        raise VcnfError("fp16 split-half matrix path clamped values at +-65504 in %d workgroup(s): "
+                        "set fused_precision = 'fp32' on the couplings (or pass model=...) and re-run" % n)
+    if n:
+        for m in model.modules():
+            if hasattr(m, "fused_precision"):
+                m.fused_precision = "fp32"
+    return n
 
 
 # ---------------------------------------------------------------- wrappers
@@ -403,7 +444,8 @@ def rqs_layer_fused(x, context, tf_idx, id_idx, ctx_dim, hidden, num_blocks, pre
                                             int(ctx_dim), int(hidden), int(num_blocks), int(precision),
                                             _ptr(wpack), wpack.numel(), _ptr(sw), _ptr(sh), _ptr(sd),
                                             ctypes.byref(cfg), int(bool(inverse)), mode, float(sign),
-                                            _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
+                                            _ptr(bad_discriminant_counter(dev)) if inverse else None,
+                                            _ptr(saturation_counter(dev)) if precision == 1 else None, _stream())
         if sink is not None:
             ev1.record()
             sink.append((ev0, ev1, b))

@@ -1,5 +1,5 @@
 // Shared pieces of the fused RQS-layer kernels (fused_layer.hip: exact fp32 matrix path;
-// fused_layer_v2.hip: fp16x3 split-half matrix path).
+// fused_layer_v6.hip: fp16x3 split-half matrix path).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,6 +23,7 @@ struct FusedArgs {
   const float* wpack;                    // packed conditioner weights, layout below
   unsigned wpack_bytes;
   int32_t* bad;
+  int32_t* sat;                          // fp16 split-half path: workgroups that clamped a value at +-65504 (or NULL)
   long long B;
   int ld_mode;
   float ld_sign;
@@ -115,17 +116,30 @@ __device__ __forceinline__ void split4v(const floatx4 v, float lower, half4& hi,
 }
 
 
-// defined in fused_layer_v2.hip
-int launch_fused_v2_c16(const FusedArgs& a, int inverse, hipStream_t st);
-int launch_fused_v2_c0(const FusedArgs& a, int inverse, hipStream_t st);
-// defined in fused_layer_v3.hip
-int launch_fused_v3_c16(const FusedArgs& a, int inverse, hipStream_t st);
-int launch_fused_v3_c0(const FusedArgs& a, int inverse, hipStream_t st);
-// defined in fused_layer_v4.hip
-int launch_fused_v4_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
-int launch_fused_v4_b2(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
-int launch_fused_v4_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
-// defined in fused_layer_v5.hip
-int launch_fused_v5_c16(const FusedArgs& a, int inverse, hipStream_t st);
+// Packed weight buffer of the fp16 split-half kernel (fused_layer_v6.hip; host side:
+// vcnf_amd/fused.py::pack_layer_h3), in floats; every matrix is stored as A fragments of
+// v_mfma_f32_32x32x16_f16: [row block of 32][k-step of 16][hi | lo][lane][8 halves] (256 floats per fragment),
+// every bias in accumulator order [row block][lane half][16].  Same total size as PackLayout.
+//   W0 | b0 | per block: WA | ba | WB | bb | (WC | bc if C > 0) |
+//   WF [group of 4 features][3 row blocks][8 k-steps][hi | lo][lane][8] | bf [group][lane half][48]
+template <int DI, int DT, int C, int H, int NBLK, int K>
+struct PackLayout6 {
+  static constexpr int NB = H / 32, NT0 = (DI + C) / 16, NTH = H / 16, NTC = C / 16, NG = DT / 4;
+  static constexpr int W0 = 0;
+  static constexpr int B0 = W0 + NB * NT0 * 512;
+  static constexpr int BLK0 = B0 + H;
+  static constexpr int WA = 0, BA = WA + NB * NTH * 512, WB = BA + H, BB = WB + NB * NTH * 512;
+  static constexpr int WC = BB + H, BC = WC + NB * NTC * 512;
+  static constexpr int BLK = (C > 0) ? BC + H : WC;
+  static constexpr int WF = BLK0 + NBLK * BLK;
+  static constexpr int BF = WF + NG * 3 * NTH * 512;
+  static constexpr int TOTAL = BF + NG * 96;
+  static_assert(TOTAL == PackLayout<DI, DT, C, H, NBLK, K>::TOTAL, "both matrix paths take a buffer of the same size");
+};
+
+// defined in fused_layer_v6.hip
+int launch_fused_v6_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
+int launch_fused_v6_b2(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
+int launch_fused_v6_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
 
 }  // namespace vcnf

@@ -326,29 +326,13 @@ extern "C" int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t
   return vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim, num_blocks) > 0 ? 1 : 0;
 }
 
-// VCNF_FUSED_KERNEL=v2|v3 selects an earlier work split of the fp16 split-half kernel (A/B timing),
-// v5 the experimental activation-stationary one (fused_layer_v5.hip; context 16, two blocks only);
-// default: v4 (fused_layer_v4.hip).
-static int fused_version() {
-  // read on every call (one getenv per launch): tests switch kernels inside one process
-  const char* e = getenv("VCNF_FUSED_KERNEL");
-  return (e && e[0] == 'v' && e[1] >= '2' && e[1] <= '5') ? e[1] - '0' : 4;
-}
-
+// fp16 split-half matrix path: fused_layer_v6.hip, one translation unit per number of residual blocks.
+// (Earlier structures v2 - v5 are kept as text under profiles/tools/superseded/; they are no longer part
+// of the library.)
 static int launch_f16x3(const FusedArgs& a, int d_id, int ctx_dim, int num_blocks, int inverse, hipStream_t st) {
-  // the earlier work splits exist for d_id = 32 with two blocks only
-  int v = (d_id == 32 && num_blocks == 2) ? fused_version() : 4;
-  if (v == 5) {
-    if (ctx_dim == 16) return launch_fused_v5_c16(a, inverse, st);
-    v = 4;
-  }
-  if (v == 4) {
-    if (num_blocks == 1) return launch_fused_v4_b1(a, d_id, ctx_dim, inverse, st);
-    if (num_blocks == 2) return launch_fused_v4_b2(a, d_id, ctx_dim, inverse, st);
-    return launch_fused_v4_b3(a, d_id, ctx_dim, inverse, st);
-  }
-  if (ctx_dim == 16) return v == 2 ? launch_fused_v2_c16(a, inverse, st) : launch_fused_v3_c16(a, inverse, st);
-  return v == 2 ? launch_fused_v2_c0(a, inverse, st) : launch_fused_v3_c0(a, inverse, st);
+  if (num_blocks == 1) return launch_fused_v6_b1(a, d_id, ctx_dim, inverse, st);
+  if (num_blocks == 2) return launch_fused_v6_b2(a, d_id, ctx_dim, inverse, st);
+  return launch_fused_v6_b3(a, d_id, ctx_dim, inverse, st);
 }
 
 extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, float* logdet,
@@ -358,7 +342,7 @@ extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, fl
                                         const float* wpack, int64_t wpack_floats,
                                         const float* shared_w, const float* shared_h, const float* shared_d,
                                         const vcnf_rqs_cfg* cfg, int inverse,
-                                        int ld_mode, float ld_sign, int32_t* bad_disc, void* stream) {
+                                        int ld_mode, float ld_sign, int32_t* bad_disc, int32_t* sat_count, void* stream) {
   if (!cfg || !wpack) return VCNF_ERR_NULL;
   if (!vcnf_rqs_layer_fused_supported(d_id, d_t, ctx_dim, hidden, num_blocks, cfg->num_bins, cfg->tails))
     return VCNF_ERR_UNSUPPORTED;
@@ -379,7 +363,7 @@ extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, fl
   a.tf_idx = transform_idx; a.id_idx = identity_idx;
   a.sh_w = shared_w; a.sh_h = shared_h; a.sh_d = shared_d;
   a.wpack = wpack; a.wpack_bytes = (unsigned)(wpack_floats * 4);
-  a.bad = bad_disc; a.B = batch; a.ld_mode = ld_mode; a.ld_sign = ld_sign;
+  a.bad = bad_disc; a.sat = sat_count; a.B = batch; a.ld_mode = ld_mode; a.ld_sign = ld_sign;
   const int K = cfg->num_bins;
   a.c.K = K; a.c.tails = cfg->tails;
   a.c.lo_x = cfg->left; a.c.hi_x = cfg->right; a.c.span_x = (float)((double)cfg->right - (double)cfg->left);

@@ -1,0 +1,159 @@
+// Rational-quadratic spline evaluation for the fused layer kernel's vector steps: the same map as
+// rqs_math.hpp::rqs_select + rqs_bin_eval (reference: normflow/utils/splines.py:88-193, linear tails :30-43)
+// with fewer vector instructions (~190 against ~290 unpacked), because the vector steps of that kernel are
+// bound by vector-instruction issue beside the partner wave's matrix instructions
+// (profiles/r02_spline_eval_microbench.md).
+//
+// The logits arrive PRE-SCALED by the host (vcnf_amd/fused.py folds the factors into the last layer's rows):
+//   width / height logits:  w' = w * (1/sqrt(hidden)) * log2(e)   (coupling.py:314-316, softmax as 2^x)
+//   derivative logits:      d' = d * log2(e)
+// and the evaluation works in "exp-sum space".  With e_k = 2^(w'_k - max), S = sum e_k and the floor m = min_w:
+//   width_k = m + (1 - K m) e_k / S = (e_k + S m / (1 - K m)) * (1 - K m) / S          (splines.py:109-110)
+// so, in units of (1 - K m) (right - left) / S, bin k is e_k + S mf wide (mf = m / (1 - K m)) and its left
+// edge is prefix_k = sum_{j<k} e_j + k S mf.  The bin search compares u = (x - left) S / ((right - left)(1 - K m))
+// with the prefix sums (no division before the search, no knots), only the selected bin is mapped back.
+// Rounding differs from the reference's cumsum order by a few ulp of the knots; the error against fp64 is the
+// same as rqs_math.hpp's (table in the profile note above).  Branch-free, no packed-f32 forms.
+#pragma once
+#include "rqs_math.hpp"
+
+namespace vcnf {
+
+struct LeanConst {
+  float lo_x, hi_x, lo_y, hi_y;
+  float kx, ky;        // 1 / ((right - left) (1 - K min_w)), same for the y side
+  float mfw, mfh;      // min / (1 - K min)
+  float sfx, sfy;      // (right - left) (1 - K min_w), y side
+  float min_d, edge2;  // edge derivative logit (splines.py:38) in log2 units
+  int tails;
+};
+
+__device__ __forceinline__ LeanConst make_lean_const(const RqsConst& c) {
+  LeanConst l;
+  l.lo_x = c.lo_x; l.hi_x = c.hi_x; l.lo_y = c.lo_y; l.hi_y = c.hi_y;
+  l.sfx = c.span_x * c.free_w;
+  l.sfy = c.span_y * c.free_h;
+  l.kx = 1.f / l.sfx;
+  l.ky = 1.f / l.sfy;
+  l.mfw = c.min_w / c.free_w;
+  l.mfh = c.min_h / c.free_h;
+  l.min_d = c.min_d;
+  l.edge2 = c.edge_logit * kLog2e;
+  l.tails = c.tails;
+  return l;
+}
+
+// min_d + softplus(v) for v2 = v log2(e):  ln2 (max(v2, 0) + log2(1 + 2^-|v2|)); the rounding error of 1 + e
+// is added back (first order), which keeps full relative accuracy when the result is tiny (splines.py:121)
+__device__ __forceinline__ float lean_derivative(float v2, float min_d) {
+  const float e = __builtin_amdgcn_exp2f(-__builtin_fabsf(v2));
+  const float u = 1.f + e;
+  const float cc = e - (u - 1.f);
+  const float l2 = __builtin_amdgcn_logf(u);
+  return min_d + fmaf(kLn2, fmaxf(v2, 0.f) + l2, cc);
+}
+
+// lg: 8 width logits, 8 height logits, 7 derivative logits (pre-scaled, see above); linear tails: a point
+// outside [lo, hi] maps to itself with log|det| 0 (evaluated at the left end, selected away afterwards).
+template <bool INV>
+__device__ __forceinline__ void rqs_lean_eval(float x, const float (&lg)[23], const LeanConst& lc,
+                                              float& yv, float& lad, bool& bad) {
+  constexpr int K = 8;
+  const bool inside = (x >= lc.lo_x) && (x <= lc.hi_x);
+  const float xi = inside ? x : lc.lo_x;
+  float ew[K], eh[K];
+  {
+    float mw = fmaxf(fmaxf(lg[0], lg[1]), lg[2]), mh = fmaxf(fmaxf(lg[8], lg[9]), lg[10]);
+    mw = fmaxf(fmaxf(mw, lg[3]), lg[4]); mh = fmaxf(fmaxf(mh, lg[11]), lg[12]);
+    mw = fmaxf(fmaxf(mw, lg[5]), lg[6]); mh = fmaxf(fmaxf(mh, lg[13]), lg[14]);
+    mw = fmaxf(mw, lg[7]); mh = fmaxf(mh, lg[15]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      ew[k] = __builtin_amdgcn_exp2f(lg[k] - mw);
+      eh[k] = __builtin_amdgcn_exp2f(lg[8 + k] - mh);
+    }
+  }
+  float cw[K], ch[K];                       // prefix sums of the softmax numerators
+  cw[0] = ew[0]; ch[0] = eh[0];
+#pragma unroll
+  for (int k = 1; k < K; ++k) { cw[k] = cw[k - 1] + ew[k]; ch[k] = ch[k - 1] + eh[k]; }
+  const float Sw = cw[K - 1], Sh = ch[K - 1];
+  const float mSw = Sw * lc.mfw, mSh = Sh * lc.mfh;
+  // a = searched side (x side in the density direction, y side in the sampling direction), b = the other
+  const float* ca = INV ? ch : cw; const float* cb = INV ? cw : ch;
+  const float* ea = INV ? eh : ew; const float* eb = INV ? ew : eh;
+  const float mSa = INV ? mSh : mSw, mSb = INV ? mSw : mSh;
+  const float Sa = INV ? Sh : Sw, Sb = INV ? Sw : Sh;
+  const float u = (xi - (INV ? lc.lo_y : lc.lo_x)) * (Sa * (INV ? lc.ky : lc.kx));
+  float selca = 0.f, selea = ea[0], selcb = 0.f, seleb = eb[0];
+  float d0 = lc.edge2, d1 = lg[16];
+#pragma unroll
+  for (int k = 1; k < K; ++k) {             // searchsorted (splines.py:12-17): last left edge that is <= u
+    const float ca_l = fmaf((float)k, mSa, ca[k - 1]);
+    const float cb_l = fmaf((float)k, mSb, cb[k - 1]);
+    const bool take = u >= ca_l;
+    selca = take ? ca_l : selca;
+    selea = take ? ea[k] : selea;
+    selcb = take ? cb_l : selcb;
+    seleb = take ? eb[k] : seleb;
+    d0 = take ? lg[16 + k - 1] : d0;
+    d1 = take ? (k == K - 1 ? lc.edge2 : lg[16 + k]) : d1;
+  }
+  const float wa = selea + mSa, wb = seleb + mSb;      // bin extents in exp-sum units
+  const float D0 = lean_derivative(d0, lc.min_d), D1 = lean_derivative(d1, lc.min_d);
+  if (!INV) {
+    // y unit gy = sfy / Sh; x unit gx = sfx / Sw; s = h / w = (wb gy) / (wa gx)          splines.py:144, 179-193
+    const float rwa = hw_rcp(wa);
+    const float rSb = hw_rcp(Sb);
+    float gy = lc.sfy * rSb; gy = fmaf(fmaf(-Sb, gy, lc.sfy), rSb, gy);
+    const float h = wb * gy;
+    const float yl = fmaf(selcb, gy, lc.lo_y);
+    const float dt = u - selca;
+    float t = dt * rwa; t = fmaf(fmaf(-wa, t, dt), rwa, t);
+    const float hn = h * (Sa * lc.kx);
+    float s = hn * rwa; s = fmaf(fmaf(-wa, s, hn), rwa, s);
+    const float omt = 1.f - t, tt = t * omt;
+    const float e = fmaf(-2.f, s, D0 + D1);
+    const float den = fmaf(e, tt, s);
+    const float num = h * fmaf(s * t, t, D0 * tt);
+    const float rden = hw_rcp(den);
+    float qn = num * rden; qn = fmaf(fmaf(-den, qn, num), rden, qn);
+    const float dn = (s * s) * fmaf(D1 * t, t, fmaf(2.f * s, tt, (D0 * omt) * omt));
+    const float l = kLn2 * fmaf(-2.f, __builtin_amdgcn_logf(den), __builtin_amdgcn_logf(dn));
+    yv = inside ? yl + qn : x;
+    lad = inside ? l : 0.f;
+  } else {
+    // searched side is y: a = heights, b = widths                                         splines.py:152-177
+    const float rSb = hw_rcp(Sb);
+    float gx = lc.sfx * rSb; gx = fmaf(fmaf(-Sb, gx, lc.sfx), rSb, gx);
+    const float w = wb * gx;
+    const float xl = fmaf(selcb, gx, lc.lo_x);
+    const float rSa = hw_rcp(Sa);
+    float gy = lc.sfy * rSa; gy = fmaf(fmaf(-Sa, gy, lc.sfy), rSa, gy);
+    const float h = wa * gy;
+    const float dy = (u - selca) * gy;
+    const float rw = hw_rcp(w);
+    float s = h * rw; s = fmaf(fmaf(-w, s, h), rw, s);
+    const float e = fmaf(-2.f, s, D0 + D1);
+    const float qa = fmaf(dy, e, h * (s - D0));
+    const float qb = fmaf(-dy, e, h * D0);
+    const float qc = -s * dy;
+    const float fa = 4.f * qa;              // b^2 - 4ac with the rounding error of 4ac recovered (Kahan)
+    const float p = fa * qc;
+    const float perr = fmaf(fa, qc, -p);
+    const float disc = fmaf(qb, qb, -p) - perr;
+    bad = bad || (inside && !(disc >= 0.f));              // :164 (the reference asserts)
+    const float dd = -qb - hw_sqrt(disc);
+    const float rdd = hw_rcp(dd);
+    const float n2 = 2.f * qc;
+    float r = n2 * rdd; r = fmaf(fmaf(-dd, r, n2), rdd, r);
+    const float omr = 1.f - r, rr = r * omr;
+    const float den = fmaf(e, rr, s);
+    const float dn = (s * s) * fmaf(D1 * r, r, fmaf(2.f * s, rr, (D0 * omr) * omr));
+    const float l = kLn2 * fmaf(2.f, __builtin_amdgcn_logf(den), -__builtin_amdgcn_logf(dn));
+    yv = inside ? fmaf(r, w, xl) : x;
+    lad = inside ? l : 0.f;
+  }
+}
+
+}  // namespace vcnf

@@ -84,58 +84,97 @@ def _as_floats(h):
     return h.contiguous().view(torch.float32).reshape(-1)
 
 
-def _pack_dense_h3(weight):
-    """Hidden->hidden layer for the fp16 matrix instruction (k-steps of 32): fragment
-    [nb][s][lane][8] holds W[16 nb + (lane & 15)][16 (2 s + (j >> 2)) + 4 (lane >> 4) + (j & 3)];
-    the hi halves of the whole layer come first, then the lo halves."""
+LOG2E = 1.4426950408889634
+
+
+def _hi_lo_fragments(w):
+    """[..., 64, 8] fp32 fragment values -> floats of [..., hi | lo, 64, 8] fp16 (two halves per float)."""
+    hi, lo = _split_halves(w)
+    return _as_floats(torch.stack([hi, lo], dim=-3))
+
+
+def _afrag_cols(k_total, chained, device):
+    """k index of slot (lane half kg, i) of k-step t for v_mfma_f32_32x32x16_f16 operands: [t, 64, 8].
+    chained: the operand is the previous layer's accumulator (register r of lane half kg is row
+    8 (r / 4) + 4 kg + r % 4 of its 32-row block, registers 8 hh .. 8 hh + 7 feed k-step 2 nb + hh);
+    otherwise the natural order 16 t + 8 kg + i of an input vector."""
+    t = torch.arange(k_total // 16, device=device).view(-1, 1, 1)
+    kg = (torch.arange(64, device=device) >> 5).view(1, -1, 1)
+    i = torch.arange(8, device=device).view(1, 1, -1)
+    cols = (16 * t + 8 * (i >> 2) + 4 * kg + (i & 3)) if chained else (16 * t + 8 * kg + i)
+    return cols.expand(k_total // 16, 64, 8)
+
+
+def _pack_dense6(weight, chained):
+    """[N, K] -> A fragments [N / 32][K / 16][hi | lo][lane][8]: lane l holds row 32 nb + l % 32."""
     n, k = weight.shape
     dev = weight.device
-    nb = torch.arange(n // 16, device=dev).view(-1, 1, 1, 1)
-    s = torch.arange(k // 32, device=dev).view(1, -1, 1, 1)
-    lane = torch.arange(64, device=dev).view(1, 1, -1, 1)
-    j = torch.arange(8, device=dev).view(1, 1, 1, -1)
-    shape = (n // 16, k // 32, 64, 8)
-    rows = (16 * nb + (lane & 15)).expand(shape)
-    cols = (16 * (2 * s + (j >> 2)) + 4 * (lane >> 4) + (j & 3)).expand(shape)
-    hi, lo = _split_halves(weight[rows, cols])
-    return torch.cat([_as_floats(hi), _as_floats(lo)])
+    cols = _afrag_cols(k, chained, dev)
+    rows = (32 * torch.arange(n // 32, device=dev).view(-1, 1, 1, 1) +
+            (torch.arange(64, device=dev) & 31).view(1, 1, -1, 1)).expand(n // 32, k // 16, 64, 8)
+    return _hi_lo_fragments(weight[rows, cols.unsqueeze(0).expand(n // 32, -1, -1, -1)])
 
 
-def _pack_final_h3(weight, bias, d_t, p):
+def _pack_bias6(bias):
+    """[N] -> accumulator order [N / 32][lane half][16]: register r of lane half kg is row 8 (r / 4) + 4 kg + r % 4."""
+    dev = bias.device
+    nb = torch.arange(bias.numel() // 32, device=dev).view(-1, 1, 1)
+    kg = torch.arange(2, device=dev).view(1, -1, 1)
+    r = torch.arange(16, device=dev).view(1, 1, -1)
+    return bias[32 * nb + 8 * (r >> 2) + 4 * kg + (r & 3)].reshape(-1)
+
+
+def _pack_final6(weight, bias, d_t, p, wh_scale, num_bins):
+    """Last layer for the fp16 split-half kernel.  Rows are permuted so that after three 32-row blocks the lane
+    half kg of a column holds the p logits of features 4 g + 2 kg + {0, 1} in accumulator entries 24 f2 + tl
+    (entry v = register v % 16 of block v / 16; tl = p is a zero row), and scaled: width / height logits by
+    wh_scale * log2(e), derivative logits by log2(e) (csrc/rqs_lean.hpp evaluates 2^x)."""
     h = weight.shape[1]
-    p4 = (p + 3) // 4
     dev = weight.device
-    g = torch.arange(d_t // 4, device=dev).view(-1, 1, 1, 1, 1)
-    b = torch.arange(p4, device=dev).view(1, -1, 1, 1, 1)
-    s = torch.arange(h // 32, device=dev).view(1, 1, -1, 1, 1)
-    lane = torch.arange(64, device=dev).view(1, 1, 1, -1, 1)
-    j = torch.arange(8, device=dev).view(1, 1, 1, 1, -1)
-    i = lane & 15
-    t = 4 * b + (i & 3)
-    shape = (d_t // 4, p4, h // 32, 64, 8)
-    rows = torch.where(t < p, (4 * g + (i >> 2)) * p + t, torch.zeros_like(t + g)).expand(shape)
-    cols = (16 * (2 * s + (j >> 2)) + 4 * (lane >> 4) + (j & 3)).expand(shape)
-    w = torch.where((t < p).expand(shape), weight[rows, cols], torch.zeros((), device=dev, dtype=weight.dtype))
-    hi, lo = _split_halves(w)
-    _, bf = _pack_final(weight, bias, d_t, p)
-    return torch.cat([_as_floats(hi), _as_floats(lo)]), bf
+    scale = torch.where(torch.arange(p, device=dev) < 2 * num_bins, wh_scale * LOG2E, LOG2E).double()
+    w = (weight.double().view(d_t, p, h) * scale.view(1, p, 1)).float()
+    bsc = (bias.double().view(d_t, p) * scale.view(1, p)).float()
+    w = torch.cat([w, torch.zeros(d_t, 1, h, device=dev)], dim=1)            # [d_t, 24, h], logit 23 = 0
+    bsc = torch.cat([bsc, torch.zeros(d_t, 1, device=dev)], dim=1)
+    g = torch.arange(d_t // 4, device=dev).view(-1, 1, 1)
+    b = torch.arange(3, device=dev).view(1, -1, 1)
+    i = torch.arange(32, device=dev).view(1, 1, -1)                          # row inside the 32-row block
+    v = 16 * b + 4 * (i >> 3) + (i & 3)                                      # accumulator entry of that row
+    feat = 4 * g + 2 * ((i >> 2) & 1) + v // 24
+    wperm = w[feat, (v % 24).expand_as(feat)].reshape(-1, h)                 # [(d_t / 4) * 96, h]
+    kg = torch.arange(2, device=dev).view(1, -1, 1)
+    v2 = torch.arange(48, device=dev).view(1, 1, -1)
+    bf = bsc[4 * g + 2 * kg + v2 // 24, (v2 % 24).expand(d_t // 4, 2, 48)]
+    return _pack_dense6(wperm, True), bf.reshape(-1)
 
 
-def pack_layer(net, d_t, p, precision=PREC_F32):
-    """Flat fp32 buffer in the layout of csrc/fused_layer.hip::PackLayout.  With
-    PREC_F16X3 the hidden->hidden and last layers hold fp16 (hi | lo) fragments in the
-    same number of bytes; the first layer and the context gates stay fp32."""
-    dense = _pack_dense_h3 if precision == PREC_F16X3 else (lambda w: _pack_dense(w, True))
+def pack_layer_h3(net, d_t, p, wh_scale, num_bins):
+    """Flat fp32 buffer in the layout of csrc/fused_common.hpp::PackLayout6 (fp16 split-half kernel): every
+    matrix as hi | lo fp16 A fragments of v_mfma_f32_32x32x16_f16, every bias in accumulator order.  Folded in:
+    the logit scale and log2(e) of the spline's exponentials (last layer, see _pack_final6) and log2(e) of the
+    gate sigmoid (context layers)."""
+    parts = [_pack_dense6(net.initial_layer.weight, False), _pack_bias6(net.initial_layer.bias)]
+    for blk in net.blocks:
+        parts += [_pack_dense6(blk.linear_layers[0].weight, True), _pack_bias6(blk.linear_layers[0].bias),
+                  _pack_dense6(blk.linear_layers[1].weight, True), _pack_bias6(blk.linear_layers[1].bias)]
+        if net.context_features:
+            wc = (blk.context_layer.weight.double() * LOG2E).float()
+            bc = (blk.context_layer.bias.double() * LOG2E).float()
+            parts += [_pack_dense6(wc, False), _pack_bias6(bc)]
+    wf, bf = _pack_final6(net.final_layer.weight, net.final_layer.bias, d_t, p, wh_scale, num_bins)
+    parts += [wf, bf]
+    return torch.cat([t.detach().reshape(-1).float() for t in parts]).contiguous()
+
+
+def pack_layer(net, d_t, p):
+    """Flat fp32 buffer in the layout of csrc/fused_common.hpp::PackLayout (exact fp32 matrix path)."""
     parts = [_pack_dense(net.initial_layer.weight, False), net.initial_layer.bias]
     for blk in net.blocks:
-        parts += [dense(blk.linear_layers[0].weight), blk.linear_layers[0].bias,
-                  dense(blk.linear_layers[1].weight), blk.linear_layers[1].bias]
+        parts += [_pack_dense(blk.linear_layers[0].weight, True), blk.linear_layers[0].bias,
+                  _pack_dense(blk.linear_layers[1].weight, True), blk.linear_layers[1].bias]
         if net.context_features:
             parts += [_pack_dense(blk.context_layer.weight, False), blk.context_layer.bias]
-    if precision == PREC_F16X3:
-        wf, bf = _pack_final_h3(net.final_layer.weight, net.final_layer.bias, d_t, p)
-    else:
-        wf, bf = _pack_final(net.final_layer.weight, net.final_layer.bias, d_t, p)
+    wf, bf = _pack_final(net.final_layer.weight, net.final_layer.bias, d_t, p)
     parts += [wf, bf]
     return torch.cat([t.detach().reshape(-1).float() for t in parts]).contiguous()
 
@@ -150,7 +189,7 @@ def eligible(coupling, context):
     from .nets.resnet import ResidualNet
     if type(net) is not ResidualNet or net.preprocessing is not None:
         return False
-    if coupling.tails != 'linear' or coupling.unconditional_transform is None and False:
+    if coupling.tails != 'linear':
         return False
     blocks = list(net.blocks)
     if any(b.use_batch_norm or not _is_relu(b.activation) or (b.dropout.p > 0 and b.training) for b in blocks):
@@ -184,7 +223,11 @@ def packed_weights(coupling):
     cache = coupling.__dict__.get('_fused_pack')
     if cache is None or cache[0] != key:
         with torch.no_grad():
-            buf = pack_layer(net, coupling.num_transform_features, coupling._transform_dim_multiplier(), prec)
+            if prec == PREC_F16X3:
+                buf = pack_layer_h3(net, coupling.num_transform_features, coupling._transform_dim_multiplier(),
+                                    coupling._cfg(True).wh_scale, coupling.num_bins)
+            else:
+                buf = pack_layer(net, coupling.num_transform_features, coupling._transform_dim_multiplier())
             if cache is not None and cache[1].shape == buf.shape and cache[1].device == buf.device:
                 cache[1].copy_(buf)
                 buf = cache[1]
