@@ -13,14 +13,20 @@ the 12-layer stack in one direction, base-distribution end cap included), plus
 the single all-reduce of [sum log_prob, count].  Weak scaling: every rank holds
 its own 1M-sample shard; no sample ever crosses ranks.
 
+Scaling modes (--scaling): "weak" (default; every rank holds its own --batch samples) and "strong" (--batch is the
+whole job, split contiguously over the ranks by vcnf_amd.shard_bounds).
+
 The JSON line also carries
-  roofline     - the RQS coupling kernel (dominant HIP kernel): algorithmic bytes
-                 per launch (3464 B per sample-layer) / mean launch
-                 duration measured with HIP events on the launch stream during the
-                 timed region, against the 8 TB/s HBM peak;
-  cpu_baseline - the CPU oracle (op-order-faithful PyTorch-CPU restatement of the
-                 reference path) timed on this box's host cores on a bounded sample
-                 of the same workload (rank 0, N=1 only).  Reported, not a target.
+  roofline     - the dominant HIP kernel of the timed region.  Fused layers (default): one kernel per layer does
+                 conditioner + splines; its work is the conditioner's algorithmic flop per launch (339 968 per
+                 sample-layer) / mean launch duration measured with HIP events on the launch stream
+                 during the timed region, against the dense f16 matrix peak / 3 (split-half operands: three
+                 matrix instructions per product) or the fp32 matrix peak (--precision fp32).  --split: the
+                 HBM-bound spline kernel, 3464 algorithmic bytes per sample-layer against 8 TB/s (and against
+                 the measured 6.3 TB/s copy rate, frac_of_measured_copy_bw);
+  cpu_baseline - the CPU oracle (op-order-faithful PyTorch-CPU restatement of the reference path) timed on this
+                 box's host cores on a bounded sample of the same workload: 1 warm-up + 3 timed runs, median
+                 (rank 0, N=1 only).  Reported, not a target.
 """
 import argparse
 import json
@@ -41,6 +47,7 @@ from vcnf_amd import _lib        # noqa: E402
 
 D, CTX, LAYERS, HIDDEN, BLOCKS, BINS, TAIL = 64, 16, 12, 128, 2, 8, 3.0
 HBM_PEAK = 8.0e12                                   # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_COPY = 6.29e12                                  # MI355X_MICROARCH.md: measured float4 copy rate
 MFMA_F32_PEAK = 157.3e12                            # MI355X_MICROARCH.md: dense fp32 matrix peak
 MFMA_F16_PEAK = 2500.0e12                           # MI355X_MICROARCH.md: dense f16/bf16 matrix peak
 P = 3 * BINS - 1
@@ -70,7 +77,14 @@ def pmc_traffic(kernel, batch):
     """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of this
     same command (profiles/*_pmc_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs,
     gfx950 correction applied there).  bench.py cannot collect counters itself; null when
-    no measurement for this kernel and batch size is on file."""
+    no measurement for this kernel and batch size is on file, or when the file was measured
+    on other kernel sources than the ones in the tree now (sha256 over vcnf_amd/csrc)."""
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    try:
+        from make_pmc_traffic import kernel_source_hash
+        current = kernel_source_hash()
+    except Exception:
+        return None
     best = None
     for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
         if not name.endswith("_pmc_hbm_traffic.json"):
@@ -79,7 +93,7 @@ def pmc_traffic(kernel, batch):
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
             continue
-        if rec.get("batch_per_launch") != batch:
+        if rec.get("batch_per_launch") != batch or rec.get("kernel_source_sha256") != current:
             continue
         vals = [v["hbm_bytes_per_launch"] for k, v in rec.get("kernels", {}).items()
                 if kernel in k and "hbm_bytes_per_launch" in v]
@@ -88,13 +102,26 @@ def pmc_traffic(kernel, batch):
     return best
 
 
+def cpu_share():
+    """Host cores this process can actually use: the scheduler affinity, cut down to the cgroup's CPU quota when
+    there is one (the GPU box shows 256 cores in the affinity mask but gives one job a 16-core share; running 256
+    threads on it took the baseline from 20 s to more than 5 minutes)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("VCNF_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(model, budget_s=20.0):
     """Oracle (kind 'port') on the host cores, bounded sample of the C3 workload."""
     from helpers import oracle_c3_stack
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     stack = oracle_c3_stack(sd, layers=LAYERS, num_bins=BINS, tail_bound=TAIL, hidden=HIDDEN)
-    # the GPU box gives one job a 16-core share; more threads than that only oversubscribe
-    cores = max(1, min(16, len(os.sched_getaffinity(0)), torch.get_num_threads()))
+    cores = cpu_share()
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(99)
 
@@ -106,15 +133,18 @@ def cpu_baseline(model, budget_s=20.0):
             stack.sample_from(eps, ctx)
         return time.perf_counter() - t0
 
-    run(512)                                   # warm-up (thread pool, allocator)
+    run(512)                                   # thread pool, allocator
     probe_b = 2048
     t = run(probe_b)
-    b = int(min(65536, max(probe_b, probe_b * (budget_s / max(t, 1e-3)))))
+    b = int(min(65536, max(probe_b, probe_b * (budget_s / 4.0 / max(t, 1e-3)))))     # 1 warm-up + 3 timed runs
     b -= b % 256
-    t = run(b)
+    run(b)                                     # warm-up at the timed size
+    ts = sorted(run(b) for _ in range(3))
+    t = ts[1]
     return {"value": round(2 * b / t, 1), "unit": "transforms/s", "cores": cores, "kind": "port",
-            "sample": "oracle C3 stack, log_prob + sample at batch %d (%.1f s), torch CPU fp32, %d threads"
-                      % (b, t, cores)}
+            "sample": "oracle C3 stack, log_prob + sample at batch %d: 1 warm-up + 3 timed runs, median %.2f s "
+                      "(min %.2f, max %.2f), torch CPU fp32, %d threads (min of scheduler affinity, cgroup CPU quota, 16-core job share)"
+                      % (b, t, ts[0], ts[2], cores)}
 
 
 def main():
@@ -122,7 +152,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1 << 20, help="samples per GPU")
+    ap.add_argument("--batch", type=int, default=1 << 20, help="samples per GPU (weak scaling) or in total (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank holds --batch samples; strong: --batch samples in total, split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split", action="store_true",
                     help="three-step layers (gather kernel, torch GEMMs, spline kernel) instead of the fused kernel")
@@ -157,8 +189,9 @@ def main():
             f.prqct.fused = not split
             f.prqct.fused_precision = precision
     route(args.split, args.precision)
-    gen = torch.Generator(device=device).manual_seed(1000 + rank)
-    B = args.batch
+    from vcnf_amd.sharded import bench_shard
+    B, seed = bench_shard(args.batch, args.scaling, rank, world)     # this rank's samples and data seed
+    gen = torch.Generator(device=device).manual_seed(seed)
     x = torch.randn(B, D, device=device, generator=gen)
     ctx = torch.randn(B, CTX, device=device, generator=gen)
     eps = torch.randn(B, D, device=device, generator=gen)
@@ -188,13 +221,30 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         _lib.EVENT_SINK = None
+        # the two directions on their own (outside the timed region): rates + harmonic combination, SURVEY 8d
+        def timed(fn, n=2):
+            fn()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            fence()
+            return (time.perf_counter() - t1) / n
+        dt_lp = timed(lambda: evaluator.reduce_stats(model.log_prob(x, ctx)))
+        dt_sm = timed(lambda: model.sample_from(eps, ctx))
     nf.check_discriminant(device)
+    saturated = nf.check_saturation(device, model=model)     # fp16 split-half path: any value clamped at +-65504?
+    assert saturated == 0, "the split-half matrix path clamped values in %d workgroup(s)" % saturated
     assert torch.isfinite(stats).all() and torch.isfinite(lq).all()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    from vcnf_amd.sharded import max_over_ranks
+    dt = max_over_ranks(dt, device)
+    dt_lp = max_over_ranks(dt_lp, device)
+    dt_sm = max_over_ranks(dt_sm, device)
+    total = torch.tensor([float(B)], dtype=torch.float64, device=device)     # samples of the whole job
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dist.all_reduce(total)
+    total = float(total.item())
 
     # dominant kernel: mean launch duration inside the timed region (HIP events on the launch stream).
     # Fused layers: one kernel per layer does conditioner + splines and is bound by the fp32 matrix
@@ -212,7 +262,7 @@ def main():
         # split-half path: every product costs three f16 matrix instructions, so the ceiling for
         # algorithmic flop is a third of the dense f16 peak
         work, peak, unit, bound, kname = (FLOP_PER_SAMPLE_LAYER * B, MFMA_F16_PEAK / 3.0, "TFLOP/s", "mfma",
-                                          "fused_rqs_layer_v4_kernel")
+                                          "fused_rqs_layer_v7_kernel")
         note = ("algorithmic flop %d per sample-layer (conditioner GEMMs); peak = dense f16 matrix peak / 3 "
                 "(hi*hi + hi*lo + lo*hi per product, 22-bit operands, fp32 accumulation); HBM side of the same "
                 "launch: %d B/sample-layer" % (FLOP_PER_SAMPLE_LAYER, 4 * D + 4 * CTX + 4 * D + 8))
@@ -242,6 +292,7 @@ def main():
         hbm_side = {"kernel": "rqs_coupling_pf_kernel (split path, not in the timed region)",
                     "achieved": round(BYTES_PER_SAMPLE_LAYER * B / t_sp / 1e9, 1), "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": round(BYTES_PER_SAMPLE_LAYER * B / t_sp / HBM_PEAK, 4),
+                    "frac_of_measured_copy_bw": round(BYTES_PER_SAMPLE_LAYER * B / t_sp / HBM_COPY, 4),
                     "avg_launch_ms": round(t_sp * 1e3, 4)}
 
     # the other matrix path of the fused kernel, same workload, outside the timed region
@@ -258,23 +309,30 @@ def main():
             torch.cuda.synchronize()
             dt_alt = (time.perf_counter() - t1) / 2
         route(args.split, args.precision)
-        other = {"matrix_path": alt, "value": round(2.0 * B / dt_alt, 1), "unit": "transforms/s",
-                 "ms_per_step": round(1e3 * dt_alt, 3)}
+        other = {"matrix_path": alt + (" (exact fp32 matrix instructions)" if alt == "fp32" else ""),
+                 "value": round(2.0 * B / dt_alt, 1), "unit": "transforms/s", "ms_per_step": round(1e3 * dt_alt, 3)}
 
     if rank == 0:
-        transforms = 2.0 * B * args.steps * world
+        transforms = 2.0 * total * args.steps
         out = {
             "metric": "flow transforms/sec (log_prob + sample), D=64 RQ-spline, batch=1M",
             "value": round(transforms / dt, 1),
             "unit": "transforms/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": ("f32 (fp16x3 split operands: 22-bit hi + lo fp16 halves, three matrix instructions per product, "
+                      "fp32 accumulate; saturation counted)" if (args.precision == "fp16x3" and not args.split) else "f32"),
+            "data": "synthetic",
+            "log_prob_rate": round(total / dt_lp, 1), "sample_rate": round(total / dt_sm, 1),
+            "harmonic_rate": round(2.0 * total / (dt_lp + dt_sm), 1),
             "config": {"workload": "C3: conditional D=64 (cond_dim=16), 12 RQ-spline coupling layers "
                                    "(8 bins), batch=%d per GPU, log_prob + sample per step" % B,
-                       "batch_per_gpu": B, "layers": LAYERS, "bins": BINS, "hidden": HIDDEN,
-                       "sharding": "batch over %d GPU(s), one all-reduce of [sum log_prob, count]" % world},
+                       "batch_per_gpu": B, "batch_total": int(total), "layers": LAYERS, "bins": BINS, "hidden": HIDDEN,
+                       "sharding": "%s scaling: %s over %d GPU(s) (contiguous shards, weights replicated), one "
+                                   "all-reduce of [sum log_prob, count] per log_prob" % (
+                                       args.scaling, ("%d samples per GPU" % B) if args.scaling == "weak" else
+                                       ("%d samples in total" % int(total)), world)},
             "roofline": {"bound": bound, "kernel": kname,
                          "achieved": round(achieved / scale, 1), "peak": peak / scale, "unit": unit,
                          "frac": round(achieved / peak, 4), "traffic": traffic,

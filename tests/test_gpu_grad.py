@@ -13,7 +13,7 @@ import torch
 import vcnf_amd as nf
 from vcnf_amd import _lib, autograd as vag
 from oracle import rqs as orqs
-from helpers import fixture, T, state_for, oracle_c3_stack, oracle_crqs_stack, within_reference_noise
+from helpers import fixture, T, state_for, oracle_c3_stack, oracle_crqs_stack, within_reference_noise, assert_close
 
 pytestmark = pytest.mark.gpu
 
@@ -265,6 +265,12 @@ def test_glow_multiscale_gradients(hip):
     model = model.to("cuda")
     _grad_compare(model.log_prob, lambda s, x: oracle_glow_multiscale(s).log_prob(x), sd, [T(fx["x"])],
                   "glow log_prob", atol=2e-3)
+    # MultiscaleFlow.forward_kld (core.py:296-308) = -mean(log_prob), differentiable
+    xg = dev(T(fx["x"]))
+    loss = model.forward_kld(xg)
+    assert_close(loss, -model.log_prob(xg).mean().detach().cpu(), rtol=1e-6, atol=1e-5, what="multiscale forward_kld")
+    loss.backward()
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in model.parameters())
 
 
 # ---------------------------------------------------------------- objectives

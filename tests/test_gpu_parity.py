@@ -19,7 +19,8 @@ import torch
 import vcnf_amd as nf
 from vcnf_amd import _lib
 from helpers import (fixture, T, state_for, assert_close, within_reference_noise, parity,
-                     oracle_rqs_coupling, oracle_c3_stack, oracle_affine_stack, glow_state)
+                     oracle_rqs_coupling, oracle_c3_stack, oracle_affine_stack, glow_state,
+                     survey71_violators, oracle_round_trip, anchored)
 from oracle import rqs as OR, layers as OL, nets as ON
 
 pytestmark = pytest.mark.gpu
@@ -257,7 +258,16 @@ def test_g5_c3_stack_log_prob_and_sample(hip, fused):
         for f in reversed(model.flows):
             zz, ld = f.inverse(zz, context=ctx)
         rec = (zz.cpu() - (eps.cpu() * torch.exp(model.q0.log_scale.cpu()) + model.q0.loc.cpu())).abs()
-        assert float(rec.mean()) < 5e-5 and float(rec.max()) < 2e-2, (float(rec.mean()), float(rec.max()))
+        # anchored to the oracle's own fp32 round trip on the same inputs (not to a constant)
+        o_lq, o_rec = oracle_round_trip(oracle_c3_stack({k: v.detach().cpu() for k, v in model.state_dict().items()}),
+                                        eps.cpu(), ctx.cpu())
+        anchored(rec, o_rec, "G5 reconstruction |z0 - base|")
+        lp_rt = model.log_prob(z, ctx)
+        anchored((lp_rt - lq).abs() / (1.0 + lq.abs()), o_lq, "G5 round trip log_q")
+        # SURVEY 7.1's elementwise criterion, reported (see helpers.survey71_violators)
+        for name, got, r32, r64 in (("log_prob", lp, "c3/lp32", "c3/lp64"), ("sample z", z, "c3/s_z32", "c3/s_z64"),
+                                    ("sample log_q", lq, "c3/s_logq32", "c3/s_logq64")):
+            assert survey71_violators(got, fx[r32], fx[r64], "G5 " + name) < 0.25
         # layer by layer through the plain Flow contract (no in-kernel accumulation)
         zz, lds = x, []
         for f in reversed(model.flows):
@@ -558,15 +568,23 @@ def test_c3_full_size_round_trip(hip, fused):
         err = (lp - lq).abs() / (1.0 + lq.abs())
         print("C3 1M round trip: log_q rel err max %.3e mean %.3e" % (float(err.max()), float(err.mean())))
         # worst element of 8e8 spline evaluations sits in a floor-derivative bin; the mean is the tight bound
-        assert float(err.max()) < 2e-2, float(err.max())
-        assert float(err.mean()) < 5e-5, float(err.mean())
         # base noise recovered by walking the flows backwards
         zz = z
         for f in reversed(model.flows):
             zz, _ = f.inverse(zz, context=ctx)
         rec = (zz - eps).abs()
         print("C3 1M reconstruction: |z0 - eps| max %.3e mean %.3e" % (float(rec.max()), float(rec.mean())))
-        assert float(rec.max()) < 5e-2 and float(rec.mean()) < 1e-5, (float(rec.max()), float(rec.mean()))
+        # yardstick: the oracle's own fp32 round trip on the first 4096 samples (the oracle cannot run 1M in
+        # seconds).  On that subset the build is held to the usual factors; over the full batch the mean to the
+        # same factor and the worst of 6.7e7 elements to 64x the oracle's worst of 2.6e5 (an extreme of a
+        # 256x larger sample of a heavy-tailed error: ill-conditioned bins amplify rounding by up to 1e3).
+        n = 4096
+        o_lq, o_rec = oracle_round_trip(oracle_c3_stack({k: v.detach().cpu() for k, v in model.state_dict().items()}),
+                                        eps[:n].cpu(), ctx[:n].cpu())
+        anchored(err[:n], o_lq, "C3 1M round trip log_q, first 4096")
+        anchored(rec[:n], o_rec, "C3 1M reconstruction, first 4096")
+        assert float(err.mean()) <= 2.0 * float(o_lq.mean()) + 1e-6 and float(err.max()) <= 64.0 * float(o_lq.max())
+        assert float(rec.mean()) <= 2.0 * float(o_rec.mean()) + 1e-6 and float(rec.max()) <= 64.0 * float(o_rec.max())
         # linearity of the log_q accumulation: accumulating into a non-zero buffer adds exactly
         part = model.flows[0].inverse(z[:4096], context=ctx[:4096])[1]
         acc = torch.full((4096,), 2.5, device="cuda")
@@ -625,16 +643,77 @@ def test_fused_path_is_taken_and_matches_split_path(hip):
     assert not fz.eligible(other.prqct, None)
 
 
-def test_fp16x3_saturates_instead_of_nan(hip):
-    """Hidden activations beyond the fp16 range saturate at +-65504 in the split-half
-    matrix path: outputs stay finite (they differ from the fp32 path there, documented)."""
+def test_fp16x3_saturation_is_counted_and_fp32_restores_parity(hip):
+    """The split-half matrix path clamps inputs, context and hidden activations at +-65504 (the reference is plain
+    fp32, nets/resnet.py:92-106).  The kernel counts workgroups that clamped; nf.check_saturation() raises, or -
+    given the model - switches the couplings to the exact fp32 matrix path, after which the oracle's result is
+    reproduced.  Hidden weights are scaled up until the counter trips."""
     torch.manual_seed(22)
-    m = set_fused(nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8).cuda().eval(), "fp16x3")
-    x = torch.randn(256, 64, device="cuda")
-    x[::7, ::2] *= 3e6          # absurd identity features -> huge hidden activations
+    m = set_fused(nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8, num_context_channels=16).cuda().eval(), "fp16x3")
+    x = torch.randn(512, 64, device="cuda")
+    ctx = torch.randn(512, 16, device="cuda")
+    nf.check_saturation()                                   # clear
     with torch.no_grad():
-        z, ld = m.inverse(x)
-    assert torch.isfinite(z).all() and torch.isfinite(ld).all()
+        m.inverse(x, context=ctx)
+    assert nf.check_saturation(model=m) == 0                # ordinary weights: nothing clamped, routing unchanged
+    assert m.prqct.fused_precision == "fp16x3"
+    tripped = False
+    with torch.no_grad():
+        for _ in range(12):
+            m.prqct.transform_net.initial_layer.weight.mul_(8.0)
+            m.prqct.transform_net.initial_layer.bias.mul_(8.0)
+            z16, ld16 = m.inverse(x, context=ctx)
+            assert torch.isfinite(z16).all() and torch.isfinite(ld16).all()     # saturates, never NaN / inf
+            try:
+                nf.check_saturation()
+            except nf.VcnfError:
+                tripped = True
+                break
+        assert tripped, "hidden activations never left the fp16 range"
+        z16, ld16 = m.inverse(x, context=ctx)
+        assert nf.check_saturation(model=m) > 0             # counted again; the model is switched to fp32
+        assert m.prqct.fused_precision == "fp32"
+        z32, ld32 = m.inverse(x, context=ctx)
+        assert nf.check_saturation(model=m) == 0
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ora = oracle_rqs_coupling(sd, "prqct.", 8, 3.0, 128)
+    with torch.no_grad():
+        zo, ldo = ora.nsf_forward(x.cpu(), ctx.cpu())
+        zo64, ldo64 = oracle_rqs_coupling({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()},
+                                          "prqct.", 8, 3.0, 128).nsf_forward(
+            x.cpu().double(), ctx.cpu().double())
+    parity(z32, zo, zo64, what="fp32 route z")
+    parity(ld32, ldo, ldo64, what="fp32 route log_det")
+    # and the clamped run really differs (that is what the counter is for)
+    assert float((ld16.cpu() - ldo).abs().max()) > 1e-3
+
+
+def test_data_mutation_needs_refresh_packed(hip):
+    """the packed weight caches key on (data_ptr, _version); ``p.data`` edits do not bump _version.
+    refresh_packed() (also run by train() / eval() / load_state_dict()) makes the fused kernel see them."""
+    torch.manual_seed(5)
+    model = set_fused(_c3_model(layers=2).cuda().eval(), "fp16x3")
+    x, ctx = torch.randn(300, 64, device="cuda"), torch.randn(300, 16, device="cuda")
+    with torch.no_grad():
+        lp0 = model.log_prob(x, ctx)
+        for p in model.flows[0].prqct.transform_net.final_layer.parameters():
+            p.data.add_(0.25)                               # behind autograd's back
+        stale = model.log_prob(x, ctx)
+        assert torch.equal(stale, lp0)                      # the documented trap
+        model.refresh_packed()
+        lp1 = model.log_prob(x, ctx)
+        split = set_fused(model, False).log_prob(x, ctx)
+    assert not torch.equal(lp1, lp0)
+    assert_close(lp1, split.cpu(), rtol=1e-5, atol=2e-4, what="fused after refresh vs split")
+    # eval() / train() transitions refresh as well
+    set_fused(model, "fp16x3")
+    with torch.no_grad():
+        for p in model.flows[1].prqct.transform_net.final_layer.parameters():
+            p.data.add_(0.25)
+        model.train(); model.eval()
+        lp2 = model.log_prob(x, ctx)
+        split2 = set_fused(model, False).log_prob(x, ctx)
+    assert_close(lp2, split2.cpu(), rtol=1e-5, atol=2e-4, what="fused after train()/eval() vs split")
 
 
 def test_g13_c5_layer_shape(hip):

@@ -288,3 +288,39 @@ def test_made_masks_and_state_keys_match_reference_fixture(tag):
                 assert np.array_equal(ours[k[len("plain/mask/"):]].numpy(), fx[k]), k
             if k.startswith("plain/int/"):
                 assert np.array_equal(ours[k[len("plain/int/"):]].numpy(), fx[k]), k
+
+
+def test_counter_device_resolution(monkeypatch):
+    """'cuda' without an index means the CURRENT device, not device 0 (a rank whose current device
+    is not 0 must read its own counters)."""
+    import torch
+    from vcnf_amd import _lib
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 3)
+    assert _lib.device_index("cuda") == 3
+    assert _lib.device_index(torch.device("cuda")) == 3
+    assert _lib.device_index("cuda:1") == 1
+    assert _lib.device_index(torch.device("cuda", 0)) == 0
+    import pytest
+    with pytest.raises(_lib.VcnfError):
+        _lib.device_index("cpu")
+
+
+def test_refresh_packed_invalidates_every_cache():
+    import torch
+    import vcnf_amd as nf
+    lay = nf.flows.CoupledRationalQuadraticSpline(8, 1, 16, 4)
+    lay.prqct.__dict__['_fused_pack'] = (("key",), torch.zeros(3))
+    lay.prqct.__dict__['_fused_final_pack'] = {'key': 1, 'buf': torch.zeros(2)}
+    lu = nf.flows.LULinearPermute(8)
+    lu.linear._mats[("k",)] = torch.zeros(1)
+    blk = nf.flows.AffineCouplingBlock(nf.nets.MLP([4, 8, 8, 8]))
+    blk.__dict__['_fused_affine_pack'] = {'key': 2, 'buf': torch.zeros(2)}
+    model = nf.NormalizingFlow(nf.distributions.DiagGaussian(8), [lay, lu, blk])
+    model.eval()                                            # train(False) runs refresh_packed
+    assert lay.prqct.__dict__['_fused_pack'][0] is None and lay.prqct.__dict__['_fused_pack'][1] is not None
+    assert lay.prqct.__dict__['_fused_final_pack']['key'] is None
+    assert blk.__dict__['_fused_affine_pack']['key'] is None
+    assert len(lu.linear._mats) == 0
+    lay.prqct.__dict__['_fused_pack'] = (("key",), torch.zeros(3))
+    model.load_state_dict(model.state_dict())
+    assert lay.prqct.__dict__['_fused_pack'][0] is None

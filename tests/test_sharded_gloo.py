@@ -33,8 +33,15 @@ def _worker(rank, world, port, out):
     lo, hi = ev.local_slice(129)
     mean = ev.mean_log_prob(x[lo:hi], ctx[lo:hi])
     stats = ev.reduce_stats(stack.log_prob(x[lo:hi], ctx[lo:hi]))
+    # bench.py's sharding and timing logic (vcnf_amd.sharded.bench_shard / max_over_ranks)
+    from vcnf_amd.sharded import bench_shard, max_over_ranks
+    weak, strong = bench_shard(1001, "weak", rank, world), bench_shard(1001, "strong", rank, world)
+    tmax = max_over_ranks(0.25 + rank, torch.device("cpu"))          # rank 1 is the slow one: 1.25 s
+    counts = torch.tensor([float(strong[0])], dtype=torch.float64)
+    dist.all_reduce(counts)
     if rank == 0:
-        torch.save({"mean": mean, "stats": stats, "span": (lo, hi)}, out)
+        torch.save({"mean": mean, "stats": stats, "span": (lo, hi), "weak": weak, "strong": strong, "tmax": tmax,
+                    "strong_total": float(counts)}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,3 +56,18 @@ def test_two_rank_mean_log_prob(tmp_path):
     assert float(got["stats"][1]) == 129.0
     assert abs(float(got["mean"]) - want.mean()) <= 1e-5 * abs(want.mean())
     assert abs(float(got["stats"][0]) - want.sum()) <= 1e-5 * abs(want.sum())
+    # bench.py: weak scaling keeps the per-rank batch, strong scaling splits it (1001 = 501 + 500); seeds differ by rank;
+    # the whole-job time is the slowest rank's
+    assert got["weak"] == (1001, 1000) and got["strong"] == (501, 1000)
+    assert got["strong_total"] == 1001.0 and got["tmax"] == 1.25
+
+
+def test_bench_shard_single_process():
+    from vcnf_amd.sharded import bench_shard, max_over_ranks
+    assert bench_shard(1 << 20, "weak", 3, 8) == (1 << 20, 1003)
+    assert sum(bench_shard(1 << 20, "strong", r, 8)[0] for r in range(8)) == 1 << 20
+    assert bench_shard(10, "strong", 7, 8)[0] == 1 and bench_shard(10, "strong", 0, 8)[0] == 2
+    assert max_over_ranks(0.5, torch.device("cpu")) == 0.5      # no process group: the local time
+    import pytest
+    with pytest.raises(ValueError):
+        bench_shard(8, "diagonal", 0, 1)

@@ -16,5 +16,6 @@ from . import utils, nets, flows, distributions                  # noqa: F401
 from .core import NormalizingFlow, MultiscaleFlow                # noqa: F401
 from .sharded import ShardedEvaluator, shard_bounds              # noqa: F401
 from .graphs import GraphedFlow                                  # noqa: F401
+from .fused import refresh_packed                                # noqa: F401
 
 __version__ = "0.1.0"

@@ -18,11 +18,29 @@ from torch import nn
 
 from .flows.affine.coupling import AffineCouplingBlock
 from .flows.mixing import Permute
+from .fused import refresh_packed
 
 
-class NormalizingFlow(nn.Module):
+class _PackedWeightsMixin:
+    """Keeps the packed weight copies of the fused kernels honest across the events that change parameters
+    behind autograd's back: train() / eval() transitions and load_state_dict() drop the caches
+    (vcnf_amd.fused.refresh_packed); after a manual ``p.data`` edit call ``refresh_packed()`` yourself."""
+
+    def _install_pack_hooks(self):
+        self.register_load_state_dict_post_hook(lambda module, incompatible: refresh_packed(module) and None)
+
+    def train(self, mode=True):
+        refresh_packed(self)
+        return super().train(mode)
+
+    def refresh_packed(self):
+        return refresh_packed(self)
+
+
+class NormalizingFlow(_PackedWeightsMixin, nn.Module):
     def __init__(self, q0, flows, p=None, categoricals=None, catlevels=None, catvdeqs=None):
         super().__init__()
+        self._install_pack_hooks()
         if categoricals is not None:
             raise NotImplementedError("variational dequantisation of categorical columns is out of scope")
         self.q0 = q0
@@ -174,13 +192,14 @@ class NormalizingFlow(nn.Module):
         self.load_state_dict(torch.load(path, weights_only=True))
 
 
-class MultiscaleFlow(nn.Module):
+class MultiscaleFlow(_PackedWeightsMixin, nn.Module):
     """Multiscale (RealNVP / Glow) container: per level a list of flows, a Merge between
     levels and one base distribution per level.  Reference: normflow/core.py:271-399
     (sample :310-340, log_prob :342-367).  Class-conditional bases are out of scope."""
 
     def __init__(self, q0, flows, merges, transform=None, class_cond=True):
         super().__init__()
+        self._install_pack_hooks()
         if class_cond and any(not hasattr(q, 'from_noise') for q in q0):
             raise NotImplementedError("class-conditional base distributions are out of scope; "
                                       "use DiagGaussian bases with class_cond=False")
@@ -195,7 +214,9 @@ class MultiscaleFlow(nn.Module):
         return -self.log_prob(x, y)
 
     def forward_kld(self, x, y=None):
-        raise NotImplementedError("training objectives need the VJP kernels (SURVEY 8f row 1)")
+        """core.py:296-308: forward KL divergence estimate -mean(log_prob); differentiable through the VJP
+        kernels of vcnf_amd.autograd."""
+        return -torch.mean(self.log_prob(x, y))
 
     def log_prob(self, x, y=None):
         """core.py:348-367: optional input transform, then per level (finest last) the

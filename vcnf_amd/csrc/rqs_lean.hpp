@@ -101,17 +101,21 @@ __device__ __forceinline__ void rqs_lean_eval(float x, const float (&lg)[23], co
   }
   const float wa = selea + mSa, wb = seleb + mSb;      // bin extents in exp-sum units
   const float D0 = lean_derivative(d0, lc.min_d), D1 = lean_derivative(d1, lc.min_d);
+  // The selected bin in x / y units, by the same operations in both directions: unit of the x side gx = sfx / Sw,
+  // of the y side gy = sfy / Sh, knots lo + prefix * unit, extents e' * unit.  (An earlier version divided in
+  // exp-sum units, (u - prefix) / e': one division less, but the two directions then saw bin edges that differ in
+  // the last bits, and inverse(forward(x)) was 2-3x less exact than the reference's round trip, which uses
+  // bit-identical knots in both directions - splines.py:109-133.)
+  const float rSw = hw_rcp(Sw), rSh = hw_rcp(Sh);
+  float gx = lc.sfx * rSw; gx = fmaf(fmaf(-Sw, gx, lc.sfx), rSw, gx);
+  float gy = lc.sfy * rSh; gy = fmaf(fmaf(-Sh, gy, lc.sfy), rSh, gy);
+  const float w = (INV ? wb : wa) * gx, h = (INV ? wa : wb) * gy;
+  const float xl = fmaf(INV ? selcb : selca, gx, lc.lo_x), yl = fmaf(INV ? selca : selcb, gy, lc.lo_y);
+  const float rw = hw_rcp(w);
+  float s = h * rw; s = fmaf(fmaf(-w, s, h), rw, s);                                  // splines.py:144
   if (!INV) {
-    // y unit gy = sfy / Sh; x unit gx = sfx / Sw; s = h / w = (wb gy) / (wa gx)          splines.py:144, 179-193
-    const float rwa = hw_rcp(wa);
-    const float rSb = hw_rcp(Sb);
-    float gy = lc.sfy * rSb; gy = fmaf(fmaf(-Sb, gy, lc.sfy), rSb, gy);
-    const float h = wb * gy;
-    const float yl = fmaf(selcb, gy, lc.lo_y);
-    const float dt = u - selca;
-    float t = dt * rwa; t = fmaf(fmaf(-wa, t, dt), rwa, t);
-    const float hn = h * (Sa * lc.kx);
-    float s = hn * rwa; s = fmaf(fmaf(-wa, s, hn), rwa, s);
+    const float dt = xi - xl;                                                          // :179
+    float t = dt * rw; t = fmaf(fmaf(-w, t, dt), rw, t);
     const float omt = 1.f - t, tt = t * omt;
     const float e = fmaf(-2.f, s, D0 + D1);
     const float den = fmaf(e, tt, s);
@@ -123,17 +127,7 @@ __device__ __forceinline__ void rqs_lean_eval(float x, const float (&lg)[23], co
     yv = inside ? yl + qn : x;
     lad = inside ? l : 0.f;
   } else {
-    // searched side is y: a = heights, b = widths                                         splines.py:152-177
-    const float rSb = hw_rcp(Sb);
-    float gx = lc.sfx * rSb; gx = fmaf(fmaf(-Sb, gx, lc.sfx), rSb, gx);
-    const float w = wb * gx;
-    const float xl = fmaf(selcb, gx, lc.lo_x);
-    const float rSa = hw_rcp(Sa);
-    float gy = lc.sfy * rSa; gy = fmaf(fmaf(-Sa, gy, lc.sfy), rSa, gy);
-    const float h = wa * gy;
-    const float dy = (u - selca) * gy;
-    const float rw = hw_rcp(w);
-    float s = h * rw; s = fmaf(fmaf(-w, s, h), rw, s);
+    const float dy = xi - yl;                                                          // :153-177
     const float e = fmaf(-2.f, s, D0 + D1);
     const float qa = fmaf(dy, e, h * (s - D0));
     const float qb = fmaf(-dy, e, h * D0);

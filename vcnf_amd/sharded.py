@@ -18,6 +18,30 @@ def shard_bounds(total, world_size, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def bench_shard(batch, scaling, rank, world_size):
+    """(samples this rank holds, seed of its synthetic data) for bench.py: 'weak' - every rank holds ``batch``
+    samples; 'strong' - ``batch`` samples in total, split by ``shard_bounds``.  The seed depends on the rank only,
+    so a rank draws different data from every other rank in both modes."""
+    if scaling == "weak":
+        n = int(batch)
+    elif scaling == "strong":
+        lo, hi = shard_bounds(batch, world_size, rank)
+        n = hi - lo
+    else:
+        raise ValueError("scaling must be 'weak' or 'strong'")
+    if not (0 <= rank < world_size):
+        raise ValueError("bad rank %d / world_size %d" % (rank, world_size))
+    return n, 1000 + rank
+
+
+def max_over_ranks(seconds, device, group=None):
+    """Whole-job duration of a timed region: the slowest rank's (one all-reduce MAX of an fp64 scalar)."""
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
 class ShardedEvaluator:
     """Wraps per-shard callables; the only collective is ``mean_log_prob``'s
     all-reduce.  ``log_prob_fn(x[, context]) -> [b]`` is normally
