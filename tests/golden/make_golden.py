@@ -122,11 +122,11 @@ def g2_tails():
 
 
 # ---------------------------------------------------------------- helpers for module cases
-def run_module_case(build, seed, inputs, call, skip=(), final_gain=6.0, weight_gain=1.0):
+def run_module_case(build, seed, inputs, call, skip=(), final_gain=6.0, weight_gain=1.0, other_gain=0.2):
     """build() -> reference module; weights are synthesised; ``call(module,
     *inputs)`` -> tuple of tensors.  Returns (entries, int_buffers, out32, out64)."""
     m = build()
-    ents = synth.load_synth(m, seed, skip=skip, final_gain=final_gain, weight_gain=weight_gain)
+    ents = synth.load_synth(m, seed, skip=skip, final_gain=final_gain, weight_gain=weight_gain, other_gain=other_gain)
     ints = synth.int_buffers(m)
     o32 = call(m, *[t.clone() for t in inputs])
     m64 = build().double()
@@ -423,20 +423,18 @@ def g12_c2_tabular():
     save("g12_c2_tabular", **out)
 
 
-# ---------------------------------------------------------------- G11 tiny Glow multiscale (C4 family)
-def g11_glow_multiscale():
+# ---------------------------------------------------------------- Glow multiscale (C4 family): G11 tiny, G20 real shape
+def glow_case(name, L, K, hidden, input_shape, batch, data_seed, weight_seed, weight_gain=0.5, other_gain=0.2):
     out = {}
-    L, K, hidden = 2, 2, 16
-    input_shape = (3, 8, 8)
-    r = rng(1100)
-    x = torch.from_numpy(r.random((16,) + input_shape, dtype=np.float32))
+    r = rng(data_seed)
+    x = torch.from_numpy(r.random((batch,) + input_shape, dtype=np.float32))
     shapes = []
     for i in range(L):
         if i > 0:
             shapes.append((input_shape[0] * 2 ** (L - i), input_shape[1] // 2 ** (L - i), input_shape[2] // 2 ** (L - i)))
         else:
             shapes.append((input_shape[0] * 2 ** (L + 1), input_shape[1] // 2 ** L, input_shape[2] // 2 ** L))
-    noise = [torch.from_numpy(r.standard_normal((16,) + sh).astype(np.float32)) for sh in shapes]
+    noise = [torch.from_numpy(r.standard_normal((batch,) + sh).astype(np.float32)) for sh in shapes]
     fixed = ("P", "sign_S", "eye", "data_dep_init_done")
 
     def build():
@@ -451,8 +449,8 @@ def g11_glow_multiscale():
                 merges += [nf.flows.Merge()]
             q0 += [nf.distributions.DiagGaussian(shapes[i])]
         m = nf.MultiscaleFlow(q0, flows, merges, class_cond=False)
-        for name, buf in m.named_buffers():
-            if name.endswith("data_dep_init_done"):
+        for name_, buf in m.named_buffers():
+            if name_.endswith("data_dep_init_done"):
                 buf.fill_(1.0)                       # no data-dependent initialisation in the fixture
         return m
 
@@ -476,14 +474,27 @@ def g11_glow_multiscale():
         return (lp, z, log_q)
     m0 = build()
     skip = tuple(k for k in m0.state_dict() if k.split(".")[-1] in fixed)
-    ents, ints, o32, o64, mref = run_module_case(build, 1101, [x] + noise, call, skip=skip, weight_gain=0.5)
+    ents, ints, o32, o64, mref = run_module_case(build, weight_seed, [x] + noise, call, skip=skip, weight_gain=weight_gain,
+                                                 other_gain=other_gain)
     pack(out, "glow", ents, ints, ["lp", "s_z", "s_logq"], o32, o64)
     for k in skip:
         out["glow/buf/" + k] = npy(mref.state_dict()[k])
     out["x"] = npy(x)
     for i, e in enumerate(noise):
         out["eps%d" % i] = npy(e)
-    save("g11_glow_multiscale", **out)
+    save(name, **out)
+
+
+def g11_glow_multiscale():
+    glow_case("g11_glow_multiscale", 2, 2, 16, (3, 8, 8), 16, 1100, 1101)
+
+
+def g20_c4_real_shape():
+    """Config C4 at its real shape (example/glow.ipynb cell 2): 3 x 32 x 32 inputs, L = 3 levels, K = 16 GlowBlocks per
+    level, 256 hidden channels; 4 images.  Weights (10.6 M floats) are synthesised on both sides."""
+    # 48 blocks deep: with the tiny model's gains (0.5 / 0.2) the reference itself overflows to -inf; these keep
+    # every block near the identity's scale
+    glow_case("g20_c4_real_shape", 3, 16, 256, (3, 32, 32), 4, 2000, 2001, weight_gain=0.1, other_gain=0.02)
 
 
 # ---------------------------------------------------------------- C5 layer shape (D=1024, K=16), 2 layers
@@ -512,6 +523,34 @@ def g13_c5_shape():
     pack(out, "c5", ents, ints, ["lp", "s_z", "s_logq"], o32, o64)
     out["x"], out["eps"] = npy(x), npy(eps)
     save("g13_c5_shape", **out)
+
+
+# ---------------------------------------------------------------- C5 at its real depth: 24 layers, D=1024, K=16
+def g21_c5_real_depth():
+    out = {}
+    r = rng(2100)
+    x = torch.from_numpy(r.standard_normal((32, 1024)).astype(np.float32))
+    eps = torch.from_numpy(r.standard_normal((32, 1024)).astype(np.float32))
+
+    def build():
+        flows = [nf.flows.CoupledRationalQuadraticSpline(1024, 2, 128, 16, reverse_mask=bool(i % 2))
+                 for i in range(24)]
+        m = nf.NormalizingFlow(nf.distributions.DiagGaussian(1024), flows)
+        m.categoricals = None
+        return m
+
+    def call(m, a, e):
+        lp = m.log_prob(a.clone())
+        z = m.q0.loc + torch.exp(m.q0.log_scale) * e
+        log_q = -0.5 * m.q0.d * np.log(2 * np.pi) - torch.sum(m.q0.log_scale + 0.5 * torch.pow(e, 2), 1)
+        for f in m.flows:
+            z, ld = f(z)
+            log_q -= ld
+        return (lp, z, log_q)
+    ents, ints, o32, o64, _ = run_module_case(build, 2101, [x, eps], call, final_gain=1.0)
+    pack(out, "c5", ents, ints, ["lp", "s_z", "s_logq"], o32, o64)
+    out["x"], out["eps"] = npy(x), npy(eps)
+    save("g21_c5_real_depth", **out)
 
 
 # ---------------------------------------------------------------- G14
@@ -713,6 +752,10 @@ def g19_autoregressive():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                            # only the named cases: make_golden.py g20_c4_real_shape ...
+        for name_ in sys.argv[1:]:
+            globals()[name_]()
+        sys.exit(0)
     g1_rqs()
     g2_tails()
     g3_crqs_layer()
@@ -732,3 +775,5 @@ if __name__ == "__main__":
     g17_image_rqs()
     g18_per_feature_tails()
     g19_autoregressive()
+    g20_c4_real_shape()
+    g21_c5_real_depth()

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 
-def synth_tensor(rng, name, shape, final_gain=6.0, weight_gain=1.0):
+def synth_tensor(rng, name, shape, final_gain=6.0, weight_gain=1.0, other_gain=0.2):
     """One fp32 tensor for state-dict entry ``name``.  Scales are chosen so the
     splines see varied bins (final conditioner layer boosted; unconditional
     spline logits N(0, 0.5^2) instead of the reference's all-equal identity
@@ -29,17 +29,17 @@ def synth_tensor(rng, name, shape, final_gain=6.0, weight_gain=1.0):
     elif leaf in ("loc", "log_scale", "s", "t"):
         z *= 0.3
     else:
-        z *= 0.2
+        z *= np.float32(other_gain)      # e.g. the L / U entries and log_S of an LU 1x1 convolution
     return torch.from_numpy(z)
 
 
-def synth_state(entries, seed, final_gain=6.0, weight_gain=1.0):
+def synth_state(entries, seed, final_gain=6.0, weight_gain=1.0, other_gain=0.2):
     """``entries``: iterable of (name, shape) in state-dict order.  ``final_gain``
     scales the last conditioner layer of RQS couplings (6: wild logits, an
     ill-conditioned stress case; 1.5: well-conditioned), ``weight_gain`` every
     other weight matrix."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    return {n: synth_tensor(rng, n, s, final_gain, weight_gain) for n, s in entries}
+    return {n: synth_tensor(rng, n, s, final_gain, weight_gain, other_gain) for n, s in entries}
 
 
 def float_entries(module):
@@ -50,11 +50,11 @@ def int_buffers(module):
     return {k: v.clone() for k, v in module.state_dict().items() if not v.is_floating_point()}
 
 
-def load_synth(module, seed, skip=(), final_gain=6.0, weight_gain=1.0):
+def load_synth(module, seed, skip=(), final_gain=6.0, weight_gain=1.0, other_gain=0.2):
     """Overwrite every floating-point state entry of ``module`` (except names in
     ``skip``) with synthetic values; returns the entry list used."""
     ents = [(k, s) for k, s in float_entries(module) if k not in skip]
-    sd = synth_state(ents, seed, final_gain, weight_gain)
+    sd = synth_state(ents, seed, final_gain, weight_gain, other_gain)
     cur = module.state_dict()
     for k, v in sd.items():
         cur[k].copy_(v.to(cur[k].dtype))

@@ -22,11 +22,11 @@ def T(a, dtype=None):
     return t if dtype is None else t.to(dtype)
 
 
-def state_for(fx, tag, seed, dtype=torch.float32, final_gain=6.0, weight_gain=1.0):
+def state_for(fx, tag, seed, dtype=torch.float32, final_gain=6.0, weight_gain=1.0, other_gain=0.2):
     """Rebuild the state dict of fixture case ``tag``: synthetic float entries
     (same PCG64 stream as the generator) + stored integer buffers."""
     ents = synth.decode_entries(fx[tag + "/entries"])
-    sd = {k: v.to(dtype) for k, v in synth.synth_state(ents, seed, final_gain, weight_gain).items()}
+    sd = {k: v.to(dtype) for k, v in synth.synth_state(ents, seed, final_gain, weight_gain, other_gain).items()}
     pre = tag + "/int/"
     for k, v in fx.items():
         if k.startswith(pre):
@@ -124,9 +124,9 @@ def oracle_glow_multiscale(sd, levels=2, blocks=2):
     return OL.Multiscale(q0, flows)
 
 
-def glow_state(fx, seed, dtype=torch.float32):
-    """State dict of fixture G11: synthetic weights (gain 0.5) + the reference's fixed buffers."""
-    sd, _ = state_for(fx, "glow", seed, dtype, weight_gain=0.5)
+def glow_state(fx, seed, dtype=torch.float32, weight_gain=0.5, other_gain=0.2):
+    """State dict of fixtures G11 / G20: synthetic weights + the reference's fixed buffers."""
+    sd, _ = state_for(fx, "glow", seed, dtype, weight_gain=weight_gain, other_gain=other_gain)
     for k, v in fx.items():
         if k.startswith("glow/buf/"):
             sd[k[len("glow/buf/"):]] = T(v, dtype)
@@ -225,7 +225,7 @@ def oracle_round_trip(stack, eps, ctx):
         lp = stack.log_prob(z, ctx)
         zz = z
         for f in reversed(stack.flows):
-            zz, _ = (f.inverse(zz, ctx) if isinstance(f, OL.RQSCoupling) else f.inverse(zz))
+            zz, _ = (f.inverse(zz, ctx) if (isinstance(f, OL.RQSCoupling) and ctx is not None) else f.inverse(zz))
         z0, _ = stack.q0.from_noise(eps)
     return (lp - lq).abs() / (1.0 + lq.abs()), (zz - z0).abs()
 

@@ -19,7 +19,7 @@ import torch
 import vcnf_amd as nf
 from vcnf_amd import _lib
 from helpers import (fixture, T, state_for, assert_close, within_reference_noise, parity,
-                     oracle_rqs_coupling, oracle_c3_stack, oracle_affine_stack, glow_state,
+                     oracle_rqs_coupling, oracle_c3_stack, oracle_crqs_stack, oracle_affine_stack, glow_state,
                      survey71_violators, oracle_round_trip, anchored)
 from oracle import rqs as OR, layers as OL, nets as ON
 
@@ -764,6 +764,70 @@ def test_g11_glow_multiscale(hip):
         parity(lq, fx["glow/s_logq32"], fx["glow/s_logq64"], rtol=1e-5, atol=1e-3, what="sample log_q")
         z2, lq2 = model.sample(5)
         assert z2.shape == (5, 3, 8, 8) and lq2.shape == (5,)
+
+
+def test_g20_c4_real_shape(hip):
+    """Config C4 at its REAL shape against the reference (fixture G20; example/glow.ipynb cell 2): 3 x 32 x 32
+    inputs, L = 3 levels, K = 16 GlowBlocks per level, 256 hidden channels - 48 affine couplings (4-D, sigmoid
+    scale map) + ActNorms on the HIP kernels, 1x1 convolutions and conv conditioners on PyTorch-ROCm."""
+    fx = fixture("g20_c4_real_shape")
+    model = load(_glow_model(levels=3, blocks=16, hidden=256, input_shape=(3, 32, 32)), glow_state(fx, 2001, weight_gain=0.1, other_gain=0.02))
+    with torch.no_grad():
+        lp = model.log_prob(dev(T(fx["x"])))
+        parity(lp, fx["glow/lp32"], fx["glow/lp64"], rtol=1e-5, atol=1e-2, what="log_prob")
+        z, lq = model.sample_from([dev(T(fx["eps%d" % i])) for i in range(3)])
+        parity(z, fx["glow/s_z32"], fx["glow/s_z64"], rtol=1e-4, atol=1e-4, what="sample z")
+        parity(lq, fx["glow/s_logq32"], fx["glow/s_logq64"], rtol=1e-5, atol=1e-2, what="sample log_q")
+        # a real batch: finite, independent of how the batch is cut, the fixture's rows reproduce their stand-alone
+        # result; sample then log_prob reproduces log_q as well as the reference's own fp32 run does on the fixture
+        torch.manual_seed(7)
+        xb = torch.rand(2048, 3, 32, 32, device="cuda")
+        xb[:4] = dev(T(fx["x"]))
+        lpb = model.log_prob(xb)
+        assert torch.isfinite(lpb).all()
+        # (not bitwise: the conditioner convolutions are library calls whose algorithm depends on the batch size)
+        assert_close(lpb[:4], lp.cpu(), rtol=2e-6, atol=1e-2, what="fixture rows inside a batch of 2048")
+        assert_close(lpb[1024:1100], model.log_prob(xb[1024:1100]).cpu(), rtol=2e-6, atol=1e-2, what="batch cut")
+        eps = [torch.randn(2048, *q.loc.shape[1:], device="cuda") for q in model.q0]
+        zb, lqb = model.sample_from(eps)
+        err = (model.log_prob(zb) - lqb).abs() / (1.0 + lqb.abs())
+        ref_rt = np.abs(fx["glow/s_logq32"] - fx["glow/s_logq64"]) / (1.0 + np.abs(fx["glow/s_logq64"]))
+        print("C4 real shape, B=2048 round trip log_q rel err: max %.3e mean %.3e (reference fp32-vs-fp64 on the "
+              "fixture: max %.3e)" % (float(err.max()), float(err.mean()), float(ref_rt.max())))
+        assert torch.isfinite(zb).all() and float(err.max()) <= 64.0 * float(ref_rt.max()) + 1e-5
+
+
+def test_g21_c5_real_depth(hip):
+    """Config C5 at its REAL depth against the reference (fixture G21): 24 RQS couplings, D = 1024, K = 16
+    (P = 47), conditioner 512 -> 24064; then the per-GPU shard's micro-batching on 32 768 samples: sample,
+    log_prob through ShardedEvaluator(micro_batch = 8192) must reproduce log_q and equal the unchunked result."""
+    fx = fixture("g21_c5_real_depth")
+    sd, _ = state_for(fx, "c5", 2101, final_gain=1.0)
+    flows = [nf.flows.CoupledRationalQuadraticSpline(1024, 2, 128, 16, reverse_mask=bool(i % 2)) for i in range(24)]
+    model = load(nf.NormalizingFlow(nf.distributions.DiagGaussian(1024), flows), sd)
+    with torch.no_grad():
+        lp = model.log_prob(dev(T(fx["x"])))
+        parity(lp, fx["c5/lp32"], fx["c5/lp64"], rtol=1e-5, atol=2e-3, what="log_prob")
+        z, lq = model.sample_from(dev(T(fx["eps"])))
+        parity(z, fx["c5/s_z32"], fx["c5/s_z64"], what="sample z")
+        parity(lq, fx["c5/s_logq32"], fx["c5/s_logq64"], rtol=1e-5, atol=2e-3, what="sample log_q")
+        assert survey71_violators(lp, fx["c5/lp32"], fx["c5/lp64"], "G21 log_prob") < 0.25
+        torch.manual_seed(11)
+        b = 32768
+        eps = torch.randn(b, 1024, device="cuda")
+        zb, lqb = model.sample_from(eps)
+        ev = nf.ShardedEvaluator(model.log_prob, micro_batch=8192)
+        lpb = ev.log_prob_shard(zb)
+        assert torch.equal(lpb[:4096], model.log_prob(zb[:4096]))            # chunking changes nothing
+        err = (lpb - lqb).abs() / (1.0 + lqb.abs())
+        # yardstick: the oracle's own fp32 round trip on the first 32 samples (24 layers of a random-weight model
+        # amplify rounding: the reference's round trip is ~3e-3 relative itself)
+        sdc = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        o_lq, _ = oracle_round_trip(oracle_crqs_stack(sdc, 24, 16, 3.0, 128), eps[:32].cpu(), None)
+        anchored(err[:32], o_lq, "C5 real depth round trip log_q, first 32")
+        print("C5 real depth, B=32768 round trip log_q rel err: max %.3e mean %.3e" % (float(err.max()), float(err.mean())))
+        assert float(err.mean()) <= 2.0 * float(o_lq.mean()) + 1e-6 and float(err.max()) <= 64.0 * float(o_lq.max())
+    nf.check_discriminant()
 
 
 def test_actnorm_data_dependent_init(hip):

@@ -227,6 +227,31 @@ def test_g11_glow_multiscale():
         assert_close(lq, fx["glow/s_logq" + suf], what="sample log_q", **tol)
 
 
+def test_g20_c4_real_shape():
+    """Config C4 at its real shape (example/glow.ipynb cell 2: 3 x 32 x 32, L = 3, K = 16 GlowBlocks per level,
+    256 hidden channels), 4 images: the oracle reproduces the reference's fp32 and fp64 outputs."""
+    fx = fixture("g20_c4_real_shape")
+    for dt, suf, tol in ((torch.float32, "32", dict(rtol=2e-5, atol=2e-2)), (torch.float64, "64", F64)):
+        sd = glow_state(fx, 2001, dt, weight_gain=0.1, other_gain=0.02)
+        ms = oracle_glow_multiscale(sd, levels=3, blocks=16)
+        assert_close(ms.log_prob(T(fx["x"], dt)), fx["glow/lp" + suf], what="log_prob", **tol)
+        z, lq = ms.sample_from([T(fx["eps%d" % i], dt) for i in range(3)])
+        assert_close(z, fx["glow/s_z" + suf], what="sample z", rtol=tol["rtol"], atol=min(tol["atol"], 1e-3))
+        assert_close(lq, fx["glow/s_logq" + suf], what="sample log_q", **tol)
+
+
+def test_g21_c5_real_depth():
+    """Config C5 at its real depth: 24 RQS couplings, D = 1024, K = 16, ResidualNet 512 -> 24064 (hidden 128, 2 blocks)."""
+    fx = fixture("g21_c5_real_depth")
+    for dt, suf, tol in ((torch.float32, "32", dict(rtol=1e-5, atol=2e-3)), (torch.float64, "64", F64)):
+        sd, _ = state_for(fx, "c5", 2101, dt, final_gain=1.0)
+        st = oracle_crqs_stack(sd, 24, 16, 3.0, 128)
+        assert_close(st.log_prob(T(fx["x"], dt)), fx["c5/lp" + suf], what="log_prob", **tol)
+        z, lq = st.sample_from(T(fx["eps"], dt))
+        assert_close(z, fx["c5/s_z" + suf], what="sample z", rtol=tol["rtol"], atol=min(tol["atol"], 2e-4))
+        assert_close(lq, fx["c5/s_logq" + suf], what="sample log_q", **tol)
+
+
 # ---------------------------------------------------------------- next rows (SURVEY 8f row 2)
 @pytest.mark.parametrize("d", [5, 64])
 def test_g14_lu_linear_permute(d):
