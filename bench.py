@@ -262,7 +262,7 @@ def main():
         # split-half path: every product costs three f16 matrix instructions, so the ceiling for
         # algorithmic flop is a third of the dense f16 peak
         work, peak, unit, bound, kname = (FLOP_PER_SAMPLE_LAYER * B, MFMA_F16_PEAK / 3.0, "TFLOP/s", "mfma",
-                                          "fused_rqs_layer_v7_kernel")
+                                          "fused_rqs_layer_v6_kernel")
         note = ("algorithmic flop %d per sample-layer (conditioner GEMMs); peak = dense f16 matrix peak / 3 "
                 "(hi*hi + hi*lo + lo*hi per product, 22-bit operands, fp32 accumulation); HBM side of the same "
                 "launch: %d B/sample-layer" % (FLOP_PER_SAMPLE_LAYER, 4 * D + 4 * CTX + 4 * D + 8))

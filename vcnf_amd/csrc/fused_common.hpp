@@ -1,5 +1,5 @@
 // Shared pieces of the fused RQS-layer kernels (fused_layer.hip: exact fp32 matrix path;
-// fused_layer_v7.hip: fp16x3 split-half matrix path).
+// fused_layer_v6.hip: fp16x3 split-half matrix path).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -116,7 +116,7 @@ __device__ __forceinline__ void split4v(const floatx4 v, float lower, half4& hi,
 }
 
 
-// Packed weight buffer of the fp16 split-half kernel (fused_layer_v7.hip; host side:
+// Packed weight buffer of the fp16 split-half kernel (fused_layer_v6.hip; host side:
 // vcnf_amd/fused.py::pack_layer_h3), in floats; every matrix is stored as A fragments of
 // v_mfma_f32_32x32x16_f16: [row block of 32][k-step of 16][hi | lo][lane][8 halves] (256 floats per fragment),
 // every bias in accumulator order [row block][lane half][16].  Same total size as PackLayout.
@@ -137,9 +137,9 @@ struct PackLayout6 {
   static_assert(TOTAL == PackLayout<DI, DT, C, H, NBLK, K>::TOTAL, "both matrix paths take a buffer of the same size");
 };
 
-// defined in fused_layer_v7.hip
-int launch_fused_v7_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
-int launch_fused_v7_b2(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
-int launch_fused_v7_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
+// defined in fused_layer_v6.hip
+int launch_fused_v6_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
+int launch_fused_v6_b2(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
+int launch_fused_v6_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
 
 }  // namespace vcnf

@@ -326,13 +326,13 @@ extern "C" int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t
   return vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim, num_blocks) > 0 ? 1 : 0;
 }
 
-// fp16 split-half matrix path: fused_layer_v7.hip, one translation unit per number of residual blocks.
+// fp16 split-half matrix path: fused_layer_v6.hip, one translation unit per number of residual blocks.
 // (Earlier structures v2 - v6 are kept as text under profiles/tools/superseded/; they are no longer part
 // of the library.)
 static int launch_f16x3(const FusedArgs& a, int d_id, int ctx_dim, int num_blocks, int inverse, hipStream_t st) {
-  if (num_blocks == 1) return launch_fused_v7_b1(a, d_id, ctx_dim, inverse, st);
-  if (num_blocks == 2) return launch_fused_v7_b2(a, d_id, ctx_dim, inverse, st);
-  return launch_fused_v7_b3(a, d_id, ctx_dim, inverse, st);
+  if (num_blocks == 1) return launch_fused_v6_b1(a, d_id, ctx_dim, inverse, st);
+  if (num_blocks == 2) return launch_fused_v6_b2(a, d_id, ctx_dim, inverse, st);
+  return launch_fused_v6_b3(a, d_id, ctx_dim, inverse, st);
 }
 
 extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, float* logdet,
