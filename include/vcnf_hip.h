@@ -246,6 +246,26 @@ int vcnf_affine_coupling_f32(const float* z, const float* param, float* out, flo
                              int32_t t_off, int32_t d_t, int scale_map, int inverse,
                              int ld_mode, float ld_sign, void* stream);
 
+/* A run of AffineCouplingBlocks with ONE conditioner shape (c_in, hidden, d_t as in
+ * vcnf_affine_layer_fused_f32) and the column permutations between them in a single launch:
+ * the reference's loop over [AffineCouplingBlock, Permute] pairs of NormalizingFlow.log_prob /
+ * .sample (core.py:150-155, :176-183; flows/affine/coupling.py:225-258; flows/mixing.py:32-54)
+ * for config C1 / C2 style stacks.  ``layers`` (HOST array, at most 16) is in EXECUTION order of the
+ * requested direction; gather_before = row of ``gathers`` [n_gather_rows][features] (device int32) whose
+ * permutation the layer's input columns go through (the layer sees z[:, row]), -1 for none;
+ * gather_after likewise for the result.  wpack = the layers' vcnf_affine_layer_fused_pack_floats
+ * buffers back to back, in the same order.  log|det| of all layers is added to / stored in logdet. */
+typedef struct {
+  int32_t cond_off, t_off, d_t;
+  int32_t gather_before;
+} vcnf_affine_stack_layer;
+int vcnf_affine_stack_fused_f32(const float* x, float* y, float* logdet, int64_t batch, int32_t features,
+                                int32_t n_layers, const vcnf_affine_stack_layer* layers, int32_t gather_after,
+                                int32_t c_in, int32_t hidden, float leaky_slope, int scale_map,
+                                const float* wpack, int64_t wpack_floats,
+                                const int32_t* gathers, int32_t n_gather_rows,
+                                int inverse, int ld_mode, float ld_sign, void* stream);
+
 /* MaskedAffineFlow.forward / .inverse (flows/affine/coupling.py:202-211 /
  * :213-222) on z[B,D]; s,t [B,D] are the scale / shift net outputs (NULL =
  * zeros, coupling.py:192-200); b[D] the 0/1 float mask.  Non-finite s/t become

@@ -406,6 +406,48 @@ def test_affine_stacks_c1_c2(hip, name, tag, layers, d, widths, seed):
         assert_close(lq, fx[tag + "/s_logq32"], what="sample log_q", **LP)
 
 
+@pytest.mark.parametrize("d,widths,mode,split,scale_map", [
+    (32, [16, 64, 64, 32], "swap", "channel", "exp"),            # config C2's stack
+    (33, [17, 32, 32, 32], "shuffle", "channel", "sigmoid"),      # odd width, random permutations
+    (2, [1, 32, 32, 2], "swap", "channel", "exp"),                # config C1's stack
+    (24, [12, 64, 64, 24], "shuffle", "channel_inv", "sigmoid_inv"),
+])
+def test_affine_stack_single_launch_matches_per_layer(hip, d, widths, mode, split, scale_map):
+    """vcnf_affine_stack_fused_f32: a run of [AffineCouplingBlock, Permute] pairs executed by ONE launch
+    (NormalizingFlow.fuse_affine_stacks, default) gives the outputs of the one-launch-per-layer path bit for bit
+    (same layer body; log|det| to rounding), in both directions, for ragged batches; the per-layer path is the one pinned to the oracle
+    and the reference's fixtures (G6, G10, G12)."""
+    torch.manual_seed(41 + d)
+    flows = []
+    for _ in range(8):
+        flows.append(nf.flows.AffineCouplingBlock(nf.nets.MLP(widths, init_zeros=False), scale_map=scale_map, split_mode=split))
+        flows.append(nf.flows.Permute(d, mode=mode))
+    model = nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows).cuda().eval()
+    for b in (1, 15, 64, 1000 + 37):
+        x, eps = torch.randn(b, d, device="cuda"), torch.randn(b, d, device="cuda")
+        with torch.no_grad():
+            model.fuse_affine_stacks = True
+            lp1 = model.log_prob(x)
+            z1, lq1 = model.sample_from(eps)
+            model.fuse_affine_stacks = False
+            lp0 = model.log_prob(x)
+            z0, lq0 = model.sample_from(eps)
+        # outputs bit for bit (same layer body); log|det| is summed over the layers in a register instead of one
+        # read-modify-write of the [B] buffer per layer: same terms, different association
+        assert torch.equal(z1, z0), (d, b)
+        assert_close(lp1, lp0.cpu(), rtol=2e-6, atol=2e-5, what="stack log_prob d=%d b=%d" % (d, b))
+        assert_close(lq1, lq0.cpu(), rtol=2e-6, atol=2e-5, what="stack sample log_q d=%d b=%d" % (d, b))
+    # a run interrupted by another flow: two launches around it, same results
+    model.flows.insert(8, nf.flows.AffineConstFlow((d,)).cuda())
+    with torch.no_grad():
+        model.flows[8].s.normal_(0, 0.3); model.flows[8].t.normal_(0, 0.3)
+        x = torch.randn(200, d, device="cuda")
+        model.fuse_affine_stacks = True
+        lp1 = model.log_prob(x)
+        model.fuse_affine_stacks = False
+        assert_close(lp1, model.log_prob(x).cpu(), rtol=2e-6, atol=2e-5, what="interrupted run")
+
+
 # ---------------------------------------------------------------- fresh inputs vs the oracle, ragged sizes
 def _oracle_pair(sd, prefix, k, tb, hid):
     o32 = oracle_rqs_coupling(sd, prefix, k, tb, hid)

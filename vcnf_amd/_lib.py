@@ -64,6 +64,8 @@ PROTOTYPES = {
                                   _P, _P, _P, ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P, _P], _INT),
     "vcnf_affine_coupling_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _INT, _INT,
                                   _INT, _F32, _P], _INT),
+    "vcnf_affine_stack_fused_f32": ([_P, _P, _P, _I64, _I32, _I32, _P, _I32, _I32, _I32, _F32, _INT, _P, _I64, _P, _I32,
+                                     _INT, _INT, _F32, _P], _INT),
     "vcnf_masked_affine_f32": ([_P, _P, _P, _P, _P, _P, _I64, _I32, _INT, _INT, _F32, _P], _INT),
     "vcnf_affine_const_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _INT, _P], _INT),
     "vcnf_permute_f32": ([_P, _P, _P, _I64, _I32, _I32, _P], _INT),
@@ -512,6 +514,36 @@ def affine_layer_fused(z, wpack, cond_off, c_in, t_off, d_t, hidden, slope, scal
                                                _ptr(in_gather), _ptr(out_gather),
                                                int(bool(inverse)), mode, float(sign), _stream())
     _check(st, "vcnf_affine_layer_fused_f32")
+    return out, logdet
+
+
+class AffineStackLayer(ctypes.Structure):
+    """vcnf_affine_stack_layer of include/vcnf_hip.h."""
+    _fields_ = [("cond_off", ctypes.c_int32), ("t_off", ctypes.c_int32), ("d_t", ctypes.c_int32),
+                ("gather_before", ctypes.c_int32)]
+
+
+def affine_stack_fused(z, wpack, layers, gather_after, gathers, c_in, hidden, slope, scale_map, inverse, logdet=None,
+                       sign=1.0):
+    """A run of AffineCouplingBlocks + the permutations between them in one kernel; csrc/fused_affine.hip.
+    ``layers``: list of (cond_off, t_off, d_t, gather_before) in execution order; ``gathers`` int32 [rows, D] or None."""
+    dev = require_device(z, wpack, logdet, gathers)
+    z = z.contiguous()
+    b, d = z.shape
+    out = torch.empty_like(z)
+    mode = LD_ACCUM
+    if logdet is None:
+        mode = LD_STORE
+        logdet = (torch.empty if scale_map != SCALE_NONE else torch.zeros)(b, dtype=torch.float32, device=dev)
+    arr = (AffineStackLayer * len(layers))(*[AffineStackLayer(*map(int, l)) for l in layers])
+    with torch.cuda.device(dev):
+        st = lib().vcnf_affine_stack_fused_f32(_ptr(z), _ptr(out), _ptr(logdet) if scale_map != SCALE_NONE else None,
+                                               b, d, len(layers), ctypes.cast(arr, ctypes.c_void_p), int(gather_after),
+                                               int(c_in), int(hidden), float(slope), int(scale_map),
+                                               _ptr(wpack), wpack.numel(), _ptr(gathers),
+                                               0 if gathers is None else int(gathers.shape[0]),
+                                               int(bool(inverse)), mode, float(sign), _stream())
+    _check(st, "vcnf_affine_stack_fused_f32")
     return out, logdet
 
 

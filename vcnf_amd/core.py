@@ -16,7 +16,8 @@ the AttributeError the reference has at this HEAD.
 import torch
 from torch import nn
 
-from .flows.affine.coupling import AffineCouplingBlock
+from .flows.affine.coupling import AffineCouplingBlock, _scale_code
+from . import fused_affine
 from .flows.mixing import Permute
 from .fused import refresh_packed
 
@@ -47,6 +48,7 @@ class NormalizingFlow(_PackedWeightsMixin, nn.Module):
         self.flows = nn.ModuleList(flows)
         self.p = p
         self.categoricals = None
+        self.fuse_affine_stacks = True           # runs of one-kernel affine layers in a single launch (fused_affine.run_stack)
 
     # ------------------------------------------------------------ density
     def log_prob(self, x, context=None):
@@ -56,11 +58,23 @@ class NormalizingFlow(_PackedWeightsMixin, nn.Module):
         z = x
         order = list(reversed(self.flows))
         skip = False
+        resume = 0                               # flows before this position were executed by a stack launch
         for i, flow in enumerate(order):
+            if i < resume:
+                continue
             if skip:
                 skip = False
                 continue
             ctx = {'context': context} if (context is not None and getattr(flow, 'takes_context', False)) else {}
+            # a run of one-kernel affine layers (and the Permutes between them) is ONE launch
+            if i >= resume and isinstance(flow, (Permute, AffineCouplingBlock)) and self.fuse_affine_stacks:
+                plan = fused_affine.plan_stack(order, i, z, True)
+                if plan is not None:
+                    resume, steps, trailing = plan
+                    core_ = steps[0][0].flows[1]
+                    z = fused_affine.run_stack(steps, trailing, z, _scale_code(core_.scale, core_.scale_map), True,
+                                               log_q, 1.0)[0]
+                    continue
             # a Permute undone right before a one-kernel affine layer becomes that kernel's load index
             if (isinstance(flow, Permute) and i + 1 < len(order) and z.dim() == 2
                     and isinstance(order[i + 1], AffineCouplingBlock) and order[i + 1].fusable(z)):
@@ -92,11 +106,22 @@ class NormalizingFlow(_PackedWeightsMixin, nn.Module):
     def _push(self, z, log_q, context):
         order = list(self.flows)
         skip = False
+        resume = 0
         for i, flow in enumerate(order):
+            if i < resume:
+                continue
             if skip:
                 skip = False
                 continue
             ctx = {'context': context} if (context is not None and getattr(flow, 'takes_context', False)) else {}
+            if i >= resume and isinstance(flow, (Permute, AffineCouplingBlock)) and self.fuse_affine_stacks:
+                plan = fused_affine.plan_stack(order, i, z, False)
+                if plan is not None:
+                    resume, steps, trailing = plan
+                    core_ = steps[0][0].flows[1]
+                    z = fused_affine.run_stack(steps, trailing, z, _scale_code(core_.scale, core_.scale_map), False,
+                                               log_q, -1.0)[0]
+                    continue
             # a Permute applied right after a one-kernel affine layer becomes that kernel's store index
             if (isinstance(flow, AffineCouplingBlock) and i + 1 < len(order) and isinstance(order[i + 1], Permute)
                     and z.dim() == 2 and flow.fusable(z)):

@@ -60,6 +60,89 @@ __device__ __forceinline__ float affine_apply(float v, float shift, float sc, in
   return divide ? v / sg + shift : v * sg + shift;
 }
 
+// Geometry of one layer inside a row strip of D floats and the float offset of its packed weights.
+struct FALayer {
+  int w_off;                 // float offset of this layer's pack inside wpack
+  int cond_off, c_in, t_off, d_t;
+};
+
+// One AffineCouplingBlock on the wave's 16-row LDS strip ``xs`` (row stride XS), in place; ``ld`` accumulates the
+// lane's share of log|det|.  (Body shared by the one-layer kernel and the stack kernel.)
+template <int KIG, int HB, int OBM>
+__device__ __forceinline__ void affine_layer_on_strip(float* xs, int XS, const __amdgpu_buffer_rsrc_t wr, const FALayer lp,
+                                                      const FusedAffineArgs& a, int voff, int qoff, int m16, int q,
+                                                      bool scaled, float& ld) {
+  const int wb = 4 * lp.w_off;               // byte offset of the layer's pack
+  // ---- layer 1: natural k order, k-step s of lane group q reads input 4 s + q
+  floatx4 h1[HB];
+  {
+    float xin[4 * KIG];
+#pragma unroll
+    for (int s = 0; s < 4 * KIG; ++s) {
+      const int c = 4 * s + q;
+      xin[s] = (s < a.KI && c < lp.c_in) ? xs[m16 * XS + lp.cond_off + c] : 0.f;
+    }
+#pragma unroll
+    for (int nb = 0; nb < HB; ++nb) {
+      floatx4 acc = wload(wr, qoff, wb + 4 * (a.off_b1 + 16 * nb));
+#pragma unroll
+      for (int g = 0; g < KIG; ++g) {
+        const floatx4 w = wload(wr, voff, wb + 4 * ((nb * KIG + g) * 256));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = mfma4(w[i], xin[4 * g + i], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h1[nb][r] = acc[r] > 0.f ? acc[r] : a.slope * acc[r];   // LeakyReLU, mlp.py:33
+    }
+  }
+  // ---- layer 2: chained k order (k-step 4 pb + r <- accumulator r of row block pb)
+  floatx4 h2[HB];
+#pragma unroll
+  for (int nb = 0; nb < HB; ++nb) {
+    floatx4 acc = wload(wr, qoff, wb + 4 * (a.off_b2 + 16 * nb));
+#pragma unroll
+    for (int pb = 0; pb < HB; ++pb) {
+      const floatx4 w = wload(wr, voff, wb + 4 * (a.off_w2 + (nb * HB + pb) * 256));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = mfma4(w[r], h1[pb][r], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h2[nb][r] = acc[r] > 0.f ? acc[r] : a.slope * acc[r];
+  }
+  // ---- layer 3 + affine map on the lane's features
+#pragma unroll
+  for (int ob = 0; ob < OBM; ++ob) {
+    if (ob < a.OB) {
+      floatx4 acc = wload(wr, qoff, wb + 4 * (a.off_b3 + 16 * ob));
+#pragma unroll
+      for (int pb = 0; pb < HB; ++pb) {
+        const floatx4 w = wload(wr, voff, wb + 4 * (a.off_w3 + (ob * HB + pb) * 256));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma4(w[r], h2[pb][r], acc);
+      }
+      if (scaled) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const int f = 8 * ob + 2 * q + pr;              // rows 4 q + 2 pr (shift), + 1 (scale)
+          if (f < lp.d_t) {
+            float* pz = xs + m16 * XS + lp.t_off + f;
+            *pz = affine_apply(*pz, acc[2 * pr], acc[2 * pr + 1], a.scale_map, a.inverse, ld);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * ob + 4 * q + r;
+          if (f < lp.d_t) {
+            float* pz = xs + m16 * XS + lp.t_off + f;
+            *pz = a.inverse ? *pz - acc[r] : *pz + acc[r];  // coupling.py:139-141 / :165-167
+          }
+        }
+      }
+    }
+  }
+}
+
 constexpr int kFABlock = 256;          // 4 waves x 16 samples
 
 // KIG: first-layer k-step groups of four (c_in <= 16 KIG); HB: hidden row blocks (hidden = 16 HB,
@@ -108,75 +191,8 @@ __global__ __launch_bounds__(kFABlock) void fused_affine_layer_kernel(const Fuse
       for (int e = lane; e < n16; e += 64) xs[e] = e < nvalid ? src[e] : 0.f;
     }
 
-    // ---- layer 1: natural k order, k-step s of lane group q reads input 4 s + q
-    floatx4 h1[HB];
-    {
-      float xin[4 * KIG];
-#pragma unroll
-      for (int s = 0; s < 4 * KIG; ++s) {
-        const int c = 4 * s + q;
-        xin[s] = (s < a.KI && c < a.c_in) ? xs[m16 * XS + a.cond_off + c] : 0.f;
-      }
-#pragma unroll
-      for (int nb = 0; nb < HB; ++nb) {
-        floatx4 acc = wload(wr, qoff, 4 * (a.off_b1 + 16 * nb));
-#pragma unroll
-        for (int g = 0; g < KIG; ++g) {
-          const floatx4 w = wload(wr, voff, 4 * ((nb * KIG + g) * 256));
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc = mfma4(w[i], xin[4 * g + i], acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h1[nb][r] = acc[r] > 0.f ? acc[r] : a.slope * acc[r];   // LeakyReLU, mlp.py:33
-      }
-    }
-    // ---- layer 2: chained k order (k-step 4 pb + r <- accumulator r of row block pb)
-    floatx4 h2[HB];
-#pragma unroll
-    for (int nb = 0; nb < HB; ++nb) {
-      floatx4 acc = wload(wr, qoff, 4 * (a.off_b2 + 16 * nb));
-#pragma unroll
-      for (int pb = 0; pb < HB; ++pb) {
-        const floatx4 w = wload(wr, voff, 4 * (a.off_w2 + (nb * HB + pb) * 256));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc = mfma4(w[r], h1[pb][r], acc);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) h2[nb][r] = acc[r] > 0.f ? acc[r] : a.slope * acc[r];
-    }
-    // ---- layer 3 + affine map on the lane's features
     float ld = 0.f;
-#pragma unroll
-    for (int ob = 0; ob < OBM; ++ob) {
-      if (ob < a.OB) {
-        floatx4 acc = wload(wr, qoff, 4 * (a.off_b3 + 16 * ob));
-#pragma unroll
-        for (int pb = 0; pb < HB; ++pb) {
-          const floatx4 w = wload(wr, voff, 4 * (a.off_w3 + (ob * HB + pb) * 256));
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc = mfma4(w[r], h2[pb][r], acc);
-        }
-        if (scaled) {
-#pragma unroll
-          for (int pr = 0; pr < 2; ++pr) {
-            const int f = 8 * ob + 2 * q + pr;              // rows 4 q + 2 pr (shift), + 1 (scale)
-            if (f < a.d_t) {
-              float* pz = xs + m16 * XS + a.t_off + f;
-              *pz = affine_apply(*pz, acc[2 * pr], acc[2 * pr + 1], a.scale_map, a.inverse, ld);
-            }
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int f = 16 * ob + 4 * q + r;
-            if (f < a.d_t) {
-              float* pz = xs + m16 * XS + a.t_off + f;
-              *pz = a.inverse ? *pz - acc[r] : *pz + acc[r];  // coupling.py:139-141 / :165-167
-            }
-          }
-        }
-      }
-    }
+    affine_layer_on_strip<KIG, HB, OBM>(xs, XS, wr, FALayer{0, a.cond_off, a.c_in, a.t_off, a.d_t}, a, voff, qoff, m16, q, scaled, ld);
     if (a.logdet) {
       ld += __shfl_xor(ld, 16, 64);
       ld += __shfl_xor(ld, 32, 64);
@@ -197,6 +213,105 @@ __global__ __launch_bounds__(kFABlock) void fused_affine_layer_kernel(const Fuse
       for (int e = lane; e < nvalid; e += 64) dst[e] = xs[e];
     }
   }
+}
+
+// A run of AffineCouplingBlocks of ONE conditioner shape, with the column permutations between them, in one launch:
+// the wave's 16 rows stay in its LDS strip from the first layer to the last (x is read once, y written once; a
+// per-layer launch streams [B, D] through HBM and pays a launch gap per layer).  A permutation is a copy between the
+// wave's two strips through its index row.
+constexpr int kFAStackMax = 16;
+struct FusedAffineStackArgs {
+  FusedAffineArgs base;          // x, y, logdet, wpack, B, D, KI, OB, scale_map, inverse, ld_*, slope, weight offsets
+  const int32_t* gathers;        // [rows][D] column index rows
+  int n_layers, gather_after;    // index row applied to the result (-1: none)
+  int layer_floats;              // floats of one layer's pack
+  FALayer layer[kFAStackMax];
+  int gather_before[kFAStackMax];   // index row applied to the columns before layer i (-1: none)
+};
+
+template <int KIG, int HB, int OBM>
+__global__ __launch_bounds__(kFABlock) void fused_affine_stack_kernel(const FusedAffineStackArgs sa) {
+  extern __shared__ __align__(16) float smem[];
+  const FusedAffineArgs& a = sa.base;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m16 = lane & 15;
+  const int q = lane >> 4;
+  const int D = a.D;
+  const __amdgpu_buffer_rsrc_t wr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpack), 0, a.wpack_bytes, 0x00020000);
+  const int voff = lane * 16;
+  const int qoff = q * 16;
+  const bool scaled = a.scale_map != VCNF_SCALE_NONE;
+  const int XS = D;
+  const int n16 = 16 * D;
+  float* s0 = smem + wave * 2 * n16;         // two strips per wave
+  float* s1 = s0 + n16;
+  const long long nwt = (a.B + 15) / 16;
+  const long long wstride = (long long)gridDim.x * (kFABlock / 64);
+  for (long long wt = (long long)blockIdx.x * (kFABlock / 64) + wave; wt < nwt; wt += wstride) {
+    const long long b0 = wt * 16;
+    const int rows = (int)min(16LL, a.B - b0);
+    const int nvalid = rows * D;
+    const float* src = a.x + b0 * D;
+    float* xs = s0;
+    float* xo = s1;
+    if ((D & 3) == 0) {
+      for (int e = 4 * lane; e < n16; e += 256) {
+        const float4 v = e < nvalid ? *reinterpret_cast<const float4*>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(xs + e) = v;
+      }
+    } else {
+      for (int e = lane; e < n16; e += 64) xs[e] = e < nvalid ? src[e] : 0.f;
+    }
+    float ld = 0.f;
+    for (int li = 0; li < sa.n_layers; ++li) {
+      const int gb = sa.gather_before[li];
+      if (gb >= 0) {                                              // flows/mixing.py:32-54 as a strip-to-strip copy
+        const int32_t* idx = sa.gathers + gb * D;
+        for (int e = lane; e < n16; e += 64) {
+          const int r = e / D, c = e - r * D;
+          xo[e] = xs[r * D + idx[c]];
+        }
+        float* t_ = xs; xs = xo; xo = t_;
+      }
+      affine_layer_on_strip<KIG, HB, OBM>(xs, XS, wr, sa.layer[li], a, voff, qoff, m16, q, scaled, ld);
+    }
+    if (sa.gather_after >= 0) {
+      const int32_t* idx = sa.gathers + sa.gather_after * D;
+      for (int e = lane; e < n16; e += 64) {
+        const int r = e / D, c = e - r * D;
+        xo[e] = xs[r * D + idx[c]];
+      }
+      float* t_ = xs; xs = xo; xo = t_;
+    }
+    if (a.logdet) {
+      ld += __shfl_xor(ld, 16, 64);
+      ld += __shfl_xor(ld, 32, 64);
+      if (q == 0 && m16 < rows) {
+        const float o = a.ld_sign * ld;
+        a.logdet[b0 + m16] = a.ld_mode ? a.logdet[b0 + m16] + o : o;
+      }
+    }
+    float* dst = a.y + b0 * D;
+    if ((D & 3) == 0) {
+      for (int e = 4 * lane; e < nvalid; e += 256) *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(xs + e);
+    } else {
+      for (int e = lane; e < nvalid; e += 64) dst[e] = xs[e];
+    }
+  }
+}
+
+template <int KIG, int HB, int OBM>
+static int launch_fa_stack(const FusedAffineStackArgs& sa, hipStream_t st) {
+  const size_t lds = (size_t)4 * 2 * 16 * sa.base.D * sizeof(float);
+  if (lds > 64 * 1024) return VCNF_ERR_SHAPE;
+  const long long ntiles = (sa.base.B + 63) / 64;
+  const long long cap = 256 * 8;
+  dim3 grid((unsigned)(ntiles < cap ? ntiles : cap));
+  hipLaunchKernelGGL((fused_affine_stack_kernel<KIG, HB, OBM>), grid, dim3(kFABlock), lds, st, sa);
+  return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }
 
 template <int KIG, int HB, int OBM>
@@ -270,4 +385,58 @@ extern "C" int vcnf_affine_layer_fused_f32(const float* x, float* y, float* logd
   if (HB == 4) { VCNF_FA(4, 4) }
   VCNF_FA(4, 8)
 #undef VCNF_FA
+}
+
+extern "C" int vcnf_affine_stack_fused_f32(const float* x, float* y, float* logdet, int64_t batch, int32_t features,
+                                           int32_t n_layers, const vcnf_affine_stack_layer* layers, int32_t gather_after,
+                                           int32_t c_in, int32_t hidden, float leaky_slope, int scale_map,
+                                           const float* wpack, int64_t wpack_floats,
+                                           const int32_t* gathers, int32_t n_gather_rows,
+                                           int inverse, int ld_mode, float ld_sign, void* stream) {
+  if (!layers || n_layers < 1 || n_layers > kFAStackMax) return VCNF_ERR_SHAPE;
+  const int d_t0 = layers[0].d_t;
+  const int n_out = scale_map == VCNF_SCALE_NONE ? d_t0 : 2 * d_t0;
+  if (batch < 0 || !fa_shape_ok(c_in, hidden, n_out, features)) return VCNF_ERR_SHAPE;
+  if (scale_map < VCNF_SCALE_EXP || scale_map > VCNF_SCALE_NONE) return VCNF_ERR_UNSUPPORTED;
+  if (ld_mode != VCNF_LD_STORE && ld_mode != VCNF_LD_ACCUM) return VCNF_ERR_UNSUPPORTED;
+  const int64_t per_layer = vcnf_affine_layer_fused_pack_floats(c_in, hidden, n_out);
+  if (wpack_floats != per_layer * n_layers) return VCNF_ERR_SHAPE;
+  if (gather_after >= n_gather_rows || gather_after < -1) return VCNF_ERR_SHAPE;
+  if (batch == 0) return VCNF_OK;
+  if (!x || !y || !wpack || (scale_map != VCNF_SCALE_NONE && !logdet) || (n_gather_rows > 0 && !gathers)) return VCNF_ERR_NULL;
+  FusedAffineStackArgs sa;
+  FusedAffineArgs& a = sa.base;
+  a.x = x; a.y = y; a.logdet = logdet; a.wpack = wpack; a.wpack_bytes = (unsigned)(wpack_floats * 4);
+  a.B = batch; a.D = features; a.c_in = c_in; a.cond_off = 0; a.d_t = d_t0; a.t_off = 0;
+  a.KI = (c_in + 3) / 4; a.OB = (n_out + 15) / 16;
+  a.scale_map = scale_map; a.inverse = inverse ? 1 : 0; a.ld_mode = ld_mode; a.ld_sign = ld_sign; a.slope = leaky_slope;
+  a.in_gather = nullptr; a.out_gather = nullptr;
+  const int KIG = c_in <= 16 ? 1 : 4, HB = hidden / 16;
+  a.off_b1 = HB * KIG * 256;
+  a.off_w2 = a.off_b1 + 16 * HB;
+  a.off_b2 = a.off_w2 + HB * HB * 256;
+  a.off_w3 = a.off_b2 + 16 * HB;
+  a.off_b3 = a.off_w3 + a.OB * HB * 256;
+  sa.gathers = gathers; sa.n_layers = n_layers; sa.gather_after = gather_after; sa.layer_floats = (int)per_layer;
+  for (int i = 0; i < n_layers; ++i) {
+    const vcnf_affine_stack_layer& l = layers[i];
+    if (l.d_t != d_t0 || l.cond_off < 0 || l.t_off < 0 || l.cond_off + c_in > features || l.t_off + l.d_t > features)
+      return VCNF_ERR_SHAPE;
+    if (l.gather_before >= n_gather_rows || l.gather_before < -1) return VCNF_ERR_SHAPE;
+    sa.layer[i] = FALayer{(int)(per_layer * i), l.cond_off, c_in, l.t_off, l.d_t};
+    sa.gather_before[i] = l.gather_before;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const bool small_out = a.OB <= 2;
+#define VCNF_FAS(KIG_, HB_)                                                             \
+  return small_out ? launch_fa_stack<KIG_, HB_, 2>(sa, st) : launch_fa_stack<KIG_, HB_, 8>(sa, st);
+  if (KIG == 1) {
+    if (HB == 2) { VCNF_FAS(1, 2) }
+    if (HB == 4) { VCNF_FAS(1, 4) }
+    VCNF_FAS(1, 8)
+  }
+  if (HB == 2) { VCNF_FAS(4, 2) }
+  if (HB == 4) { VCNF_FAS(4, 4) }
+  VCNF_FAS(4, 8)
+#undef VCNF_FAS
 }

@@ -114,3 +114,74 @@ def run(block, z, code, inverse, log_q=None, sign=1.0, in_gather=None, out_gathe
         cond_off, t_off, d_t = head, 0, head
     return _lib.affine_layer_fused(z, buf, cond_off, l1.in_features, t_off, d_t, l1.out_features, slope, code,
                                    inverse, logdet=log_q, sign=sign, in_gather=in_gather, out_gather=out_gather)
+
+
+STACK_MAX = 16
+
+
+def _geometry(block, c):
+    head = c - c // 2
+    return (0, head, c - head) if block.split_mode == 'channel' else (head, 0, head)
+
+
+def plan_stack(order, start, z, inverse):
+    """Longest run order[start:end] of one-kernel-eligible AffineCouplingBlocks of ONE conditioner shape, with at most
+    one Permute between neighbours (and optionally before the first / after the last), that
+    ``vcnf_affine_stack_fused_f32`` can execute in a single launch.  Returns (end, steps, trailing_permute) with
+    steps = [(block, permute_before or None)], or None when the run has fewer than two blocks."""
+    from .flows.affine.coupling import AffineCouplingBlock
+    from .flows.mixing import Permute
+    if z.dim() != 2:
+        return None
+    steps, pending, j, shape = [], None, start, None
+    while j < len(order) and len(steps) < STACK_MAX:
+        f = order[j]
+        if isinstance(f, Permute) and pending is None:
+            pending = f
+            j += 1
+            continue
+        if isinstance(f, AffineCouplingBlock) and f.fusable(z):
+            (l1, l2, l3), slope = _linears(f.flows[1].param_map)
+            core = f.flows[1]
+            sh = (l1.in_features, l1.out_features, l3.out_features, slope, core.scale, core.scale_map,
+                  _geometry(f, z.shape[1])[2])
+            if shape is None:
+                shape = sh
+            if sh == shape:
+                steps.append((f, pending))
+                pending = None
+                j += 1
+                continue
+        break
+    # a permutation still pending here executes right after the run's last block: the kernel applies it to its result
+    if len(steps) < 2:
+        return None
+    return j, steps, pending
+
+
+def run_stack(steps, trailing, z, code, inverse, log_q, sign):
+    """Execute a planned run (see plan_stack) in one launch."""
+    first = steps[0][0]
+    (l1, _, l3), slope = _linears(first.flows[1].param_map)
+    bufs = [packed_weights(b)[0] for b, _ in steps]
+    cache = first.__dict__.setdefault('_fused_affine_stack', {})
+    key = (bool(inverse), tuple(id(b) for b, _ in steps), tuple(t.data_ptr() for t in bufs),
+           tuple(b.__dict__['_fused_affine_pack']['key'] for b, _ in steps))
+    if cache.get('key') != key:
+        cache['key'] = key
+        cache['wpack'] = torch.cat(bufs).contiguous()
+    rows, layers = [], []
+    for blk, perm in steps:
+        gb = -1
+        if perm is not None:
+            gb = len(rows)
+            rows.append(perm._idx32(inverse, z.device))
+        cond_off, t_off, d_t = _geometry(blk, z.shape[1])
+        layers.append((cond_off, t_off, d_t, gb))
+    ga = -1
+    if trailing is not None:
+        ga = len(rows)
+        rows.append(trailing._idx32(inverse, z.device))
+    gathers = torch.stack(rows).contiguous() if rows else None
+    return _lib.affine_stack_fused(z, cache['wpack'], layers, ga, gathers, l1.in_features, l1.out_features, slope, code,
+                                   inverse, logdet=log_q, sign=sign)
