@@ -147,6 +147,113 @@ def cpu_baseline(model, budget_s=20.0):
                       % (b, t, ts[0], ts[2], cores)}
 
 
+def bench_other(args, device, rank, world):
+    """BASELINE.json's configurations C2 and C5 (one line each, same schema; not the headline metric)."""
+    from vcnf_amd.sharded import max_over_ranks
+    torch.manual_seed(0)
+    if args.config == "C2":
+        d, layers, B = 32, 8, 262144 if args.batch == 1 << 20 else args.batch
+        flows = []
+        for _ in range(layers):
+            flows += [nf.flows.AffineCouplingBlock(nf.nets.MLP([16, 64, 64, 32], init_zeros=False), scale_map="exp"),
+                      nf.flows.Permute(d, mode="swap")]
+        flop_sl, bytes_sl = 2 * (16 * 64 + 64 * 64 + 64 * 32), 264           # per sample-layer, SURVEY 8d
+        tag, kname = "affine_stack_fused", "fused_affine_stack_kernel"
+        # one launch = the whole stack in one direction; its conditioner MLPs run on exact fp32 matrix instructions
+        work, peak, unit, bound = flop_sl * layers, MFMA_F32_PEAK, "TFLOP/s", "mfma"
+        hbm_bytes = 4 * d * 2 + 8                                             # x once, y once, log_q
+        workload = "C2: tabular D=32, 8 affine couplings (MLP 16-64-64-32) + swap permutations, batch=%d per GPU" % B
+        dtype = "f32"
+    else:
+        d, layers, B = 1024, 24, 16384 if args.batch == 1 << 20 else args.batch
+        flows = [nf.flows.CoupledRationalQuadraticSpline(d, 2, 128, 16, reverse_mask=bool(i % 2)) for i in range(layers)]
+        flop_sl, bytes_sl = 2 * (512 * 128 + 4 * 128 * 128 + 128 * 512 * 47), 104456
+        tag, kname = "rqs_final_fused", "fused_final_kernel"
+        work, peak, unit, bound = bytes_sl, HBM_PEAK, "GB/s", "hbm"          # SURVEY 8d yardstick for C5: operator-boundary bytes
+        hbm_bytes = None
+        workload = ("C5: D=1024, 24 RQS couplings (16 bins, ResidualNet 512 -> 24064), micro-batch %d per step "
+                    "(the 524288-sample per-GPU shard is walked in such pieces)" % B)
+        dtype = "f32 (last conditioner layer: fp16x3 split operands, fp32 accumulate; trunk fp32)"
+    model = nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows).to(device).eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "unnormalized_" in n:
+                p.normal_(0.0, 0.5)
+    gen = torch.Generator(device=device).manual_seed(1000 + rank)
+    x = torch.randn(B, d, device=device, generator=gen)
+    eps = torch.randn(B, d, device=device, generator=gen)
+    evaluator = nf.ShardedEvaluator(model.log_prob)
+
+    def step():
+        stats = evaluator.reduce_stats(model.log_prob(x))
+        z, lq = model.sample_from(eps)
+        return stats, lq
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        events = []
+        _lib.EVENT_SINK = events
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            stats, lq = step()
+        fence()
+        dt = max_over_ranks(time.perf_counter() - t0, device)
+        _lib.EVENT_SINK = None
+    nf.check_discriminant(device)
+    assert torch.isfinite(stats).all() and torch.isfinite(lq).all()
+    durs = [a.elapsed_time(b) * 1e-3 for a, b, t in events if t == tag]
+    kern_s = sum(durs) / max(len(durs), 1)
+    per_launch = work * B
+    scale = 1e9 if unit == "GB/s" else 1e12
+    if rank == 0:
+        out = {"metric": "flow transforms/sec (log_prob + sample), config %s" % args.config,
+               "value": round(2.0 * B * world * args.steps / dt, 1), "unit": "transforms/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+               "config": {"workload": workload, "batch_per_gpu": B, "layers": layers},
+               "roofline": {"bound": bound, "kernel": kname, "achieved": round(per_launch / kern_s / scale, 1) if durs else 0.0,
+                            "peak": peak / scale, "unit": unit,
+                            "frac": round(per_launch / kern_s / peak, 4) if durs else 0.0, "traffic": None,
+                            "launches": len(durs), "avg_launch_ms": round(kern_s * 1e3, 4),
+                            "algorithmic_work_per_launch": per_launch,
+                            "note": ("algorithmic flop %d per sample-layer x %d layers per launch (MLP conditioners on "
+                                     "v_mfma_f32_16x16x4_f32); HBM side of a launch: %d B per sample (%.1f us at 8 TB/s)"
+                                     % (flop_sl, layers, hbm_bytes, 1e6 * hbm_bytes * B / HBM_PEAK)) if args.config == "C2" else
+                                    ("operator-boundary bytes %d per sample-layer (x + the [d_t, 3K-1] logits + y + log_q, "
+                                     "SURVEY 8d) per launch of the last-layer + spline kernel; the logits never reach "
+                                     "HBM in this path, so this is the yardstick, not the traffic" % bytes_sl)}}
+        if world == 1 and not args.no_cpu_baseline and args.config == "C2":
+            from helpers import oracle_affine_stack
+            sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            stack = oracle_affine_stack(sd, layers, d)
+            cores = cpu_share()
+            torch.set_num_threads(cores)
+            xc, ec = x.cpu(), eps.cpu()
+
+            def run():
+                t1 = time.perf_counter()
+                with torch.no_grad():
+                    stack.log_prob(xc)
+                    stack.sample_from(ec)
+                return time.perf_counter() - t1
+            run()
+            ts = sorted(run() for _ in range(3))
+            out["cpu_baseline"] = {"value": round(2 * B / ts[1], 1), "unit": "transforms/s", "cores": cores, "kind": "port",
+                                   "sample": "oracle C2 stack at the full batch %d, 1 warm-up + 3 timed runs, median %.2f s, "
+                                             "torch CPU fp32, %d threads" % (B, ts[1], cores)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +262,10 @@ def main():
     ap.add_argument("--batch", type=int, default=1 << 20, help="samples per GPU (weak scaling) or in total (strong)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: every rank holds --batch samples; strong: --batch samples in total, split over the ranks")
+    ap.add_argument("--config", choices=["C3", "C2", "C5"], default="C3",
+                    help="C3 (default) is the headline metric's configuration; C2 (D=32, 8 affine couplings, batch 262144) "
+                         "and C5 (D=1024, 24 RQS couplings, 16 bins, per-GPU micro-batch 16384) are BASELINE.json's other "
+                         "GPU configurations, reported with their own roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split", action="store_true",
                     help="three-step layers (gather kernel, torch GEMMs, spline kernel) instead of the fused kernel")
@@ -182,6 +293,8 @@ def main():
         else:
             dist.init_process_group(backend)
     nf.lib()
+    if args.config != "C3":
+        return bench_other(args, device, rank, world)
 
     model = build_model(device, seed=0)                      # replicated weights
     def route(split, precision):

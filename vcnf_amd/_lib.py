@@ -194,6 +194,26 @@ def _counter(table, device):
     return table[key]
 
 
+class _timed:
+    """bench.py hook: with EVENT_SINK set to a list, brackets a kernel launch with HIP events on the launch stream
+    (torch's current stream = the stream the kernel is enqueued on) and appends (start, end, tag)."""
+
+    def __init__(self, tag):
+        self.tag, self.sink = tag, EVENT_SINK
+
+    def __enter__(self):
+        if self.sink is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.sink is not None:
+            self.e1.record()
+            self.sink.append((self.e0, self.e1, self.tag))
+        return False
+
+
 def bad_discriminant_counter(device):
     """Device int32 that the inverse spline kernels bump when b^2-4ac < 0 (the
     reference asserts on the host, splines.py:164)."""
@@ -487,7 +507,7 @@ def rqs_final_fused(x, h, out, tf_idx, d_t, hidden, wpack, cfg, inverse):
     b, d = x.shape
     rows = int(lib().vcnf_rqs_final_fused_partial_rows(d_t, cfg.num_bins))
     partial = torch.empty(rows, b, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("rqs_final_fused"):
         st = lib().vcnf_rqs_final_fused_f32(_ptr(x), _ptr(h), _ptr(out), _ptr(partial), b, d, _ptr(tf_idx), int(d_t),
                                             int(hidden), _ptr(wpack), wpack.numel(), ctypes.byref(cfg),
                                             int(bool(inverse)),
@@ -536,7 +556,7 @@ def affine_stack_fused(z, wpack, layers, gather_after, gathers, c_in, hidden, sl
         mode = LD_STORE
         logdet = (torch.empty if scale_map != SCALE_NONE else torch.zeros)(b, dtype=torch.float32, device=dev)
     arr = (AffineStackLayer * len(layers))(*[AffineStackLayer(*map(int, l)) for l in layers])
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("affine_stack_fused"):
         st = lib().vcnf_affine_stack_fused_f32(_ptr(z), _ptr(out), _ptr(logdet) if scale_map != SCALE_NONE else None,
                                                b, d, len(layers), ctypes.cast(arr, ctypes.c_void_p), int(gather_after),
                                                int(c_in), int(hidden), float(slope), int(scale_map),
