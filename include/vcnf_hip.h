@@ -163,6 +163,17 @@ int vcnf_rqs_final_fused_f32(const float* x, const float* h, float* y, float* pa
                              int32_t hidden, const float* wpack, int64_t wpack_floats,
                              const vcnf_rqs_cfg* cfg, int inverse, int32_t* bad_discriminant, void* stream);
 
+/* Trunk of a ResidualNet conditioner in one launch: h[B, 128] = everything in front of final_layer
+ * (nets/resnet.py:92-105: initial_layer, then per block h += linear_1(relu(linear_0(relu(h)))), ReLU, no batch
+ * norm, dropout 0, no context gate) for x[B, d_in] = the (identity | context) input, d_in a multiple of 16,
+ * hidden 128, 1-3 blocks; exact fp32 matrix instructions.  Feeds vcnf_rqs_final_fused_f32 (config C5).
+ * wpack: vcnf_resnet_trunk_pack_floats floats, every weight matrix as [row block of 16][k block of 16][lane][4]
+ * fragments (k = 16 kb + 4 (lane >> 4) + c), biases in natural order (vcnf_amd/fused_final.py::pack_trunk). */
+int vcnf_resnet_trunk_supported(int32_t d_in, int32_t hidden, int32_t num_blocks);
+int64_t vcnf_resnet_trunk_pack_floats(int32_t d_in, int32_t hidden, int32_t num_blocks);
+int vcnf_resnet_trunk_f32(const float* x, float* h, int64_t batch, int32_t d_in, int32_t hidden,
+                          int32_t num_blocks, const float* wpack, int64_t wpack_floats, void* stream);
+
 /* One RQS coupling layer on x[B,D] -> y[B,D].
  * Replaces Coupling.forward / .inverse (flows/neural_spline/coupling.py:70-96 /
  * :98-125) minus the conditioner call, PiecewiseCoupling._coupling_transform

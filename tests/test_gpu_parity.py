@@ -839,6 +839,35 @@ def test_g20_c4_real_shape(hip):
         assert torch.isfinite(zb).all() and float(err.max()) <= 64.0 * float(ref_rt.max()) + 1e-5
 
 
+@pytest.mark.parametrize("d_in,blocks", [(512, 2), (16, 1), (80, 3)])
+def test_resnet_trunk_kernel_vs_torch(hip, d_in, blocks):
+    """csrc/resnet_trunk.hip (ResidualNet trunk in one launch, exact fp32 matrix instructions) against the module's own
+    PyTorch evaluation and the oracle's fp64 (nets/resnet.py:92-105), ragged batches."""
+    from vcnf_amd import fused_final
+    torch.manual_seed(100 + d_in)
+    m = nf.flows.CoupledRationalQuadraticSpline(2 * d_in, blocks, 128, 16).cuda().eval()
+    net = m.prqct.transform_net
+    with torch.no_grad():
+        for p in net.parameters():
+            p.normal_(0, 0.2)
+    sd64 = {k[len("prqct.transform_net."):]: v.detach().double().cpu() for k, v in m.state_dict().items()
+            if k.startswith("prqct.transform_net.")}
+    for b in (1, 17, 1024 + 5):
+        x = torch.randn(b, d_in, device="cuda")
+        with torch.no_grad():
+            assert fused_final.trunk_eligible(net, x, None)
+            got = _lib.resnet_trunk(x, fused_final.packed_trunk(m.prqct), 128, blocks)
+            ref32 = net.hidden(x)
+            h64 = x.double().cpu() @ sd64["initial_layer.weight"].t() + sd64["initial_layer.bias"]
+            for i in range(blocks):
+                t = torch.relu(h64) @ sd64["blocks.%d.linear_layers.0.weight" % i].t() + sd64["blocks.%d.linear_layers.0.bias" % i]
+                t = torch.relu(t) @ sd64["blocks.%d.linear_layers.1.weight" % i].t() + sd64["blocks.%d.linear_layers.1.bias" % i]
+                h64 = h64 + t
+        scale = float(h64.abs().max())
+        e_got, e_ref = float((got.double().cpu() - h64).abs().max()), float((ref32.double().cpu() - h64).abs().max())
+        assert e_got <= 2.0 * e_ref + 1e-6 * scale, (d_in, b, e_got, e_ref)
+
+
 def test_g21_c5_real_depth(hip):
     """Config C5 at its REAL depth against the reference (fixture G21): 24 RQS couplings, D = 1024, K = 16
     (P = 47), conditioner 512 -> 24064; then the per-GPU shard's micro-batching on 32 768 samples: sample,

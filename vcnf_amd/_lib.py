@@ -64,6 +64,9 @@ PROTOTYPES = {
                                   _P, _P, _P, ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P, _P], _INT),
     "vcnf_affine_coupling_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _INT, _INT,
                                   _INT, _F32, _P], _INT),
+    "vcnf_resnet_trunk_supported": ([_I32, _I32, _I32], _INT),
+    "vcnf_resnet_trunk_pack_floats": ([_I32, _I32, _I32], _I64),
+    "vcnf_resnet_trunk_f32": ([_P, _P, _I64, _I32, _I32, _I32, _P, _I64, _P], _INT),
     "vcnf_affine_stack_fused_f32": ([_P, _P, _P, _I64, _I32, _I32, _P, _I32, _I32, _I32, _F32, _INT, _P, _I64, _P, _I32,
                                      _INT, _INT, _F32, _P], _INT),
     "vcnf_masked_affine_f32": ([_P, _P, _P, _P, _P, _P, _I64, _I32, _INT, _INT, _F32, _P], _INT),
@@ -514,6 +517,19 @@ def rqs_final_fused(x, h, out, tf_idx, d_t, hidden, wpack, cfg, inverse):
                                             _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
     _check(st, "vcnf_rqs_final_fused_f32")
     return partial
+
+
+def resnet_trunk(x, wpack, hidden, num_blocks):
+    """ResidualNet trunk (initial layer + residual blocks) in one kernel; csrc/resnet_trunk.hip.  x [B, d_in] -> h [B, hidden]."""
+    dev = require_device(x, wpack)
+    x = x.contiguous()
+    b, d_in = x.shape
+    h = torch.empty(b, hidden, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("resnet_trunk"):
+        st = lib().vcnf_resnet_trunk_f32(_ptr(x), _ptr(h), b, int(d_in), int(hidden), int(num_blocks), _ptr(wpack),
+                                         wpack.numel(), _stream())
+    _check(st, "vcnf_resnet_trunk_f32")
+    return h
 
 
 def affine_layer_fused(z, wpack, cond_off, c_in, t_off, d_t, hidden, slope, scale_map, inverse, logdet=None,

@@ -177,6 +177,7 @@ class PiecewiseRationalQuadraticCoupling(Flow):
         # matrix path of the fused kernel: 'fp32' (exact fp32 fma chains) or 'fp16x3'
         # (hi/lo split halves on the fp16 matrix cores, 22 significant bits, ~5x the rate)
         self.fused_precision = None      # None: vcnf_amd.fused.DEFAULT_PRECISION
+        self.fused_trunk = True          # conditioner trunk in one launch where csrc/resnet_trunk.hip covers it
 
     @property
     def num_identity_features(self):

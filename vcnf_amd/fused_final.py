@@ -79,6 +79,49 @@ def packed_weights(coupling):
     return cache['buf']
 
 
+def trunk_eligible(net, first_in, context):
+    """ResidualNet trunks the one-launch kernel (csrc/resnet_trunk.hip) covers: hidden 128, ReLU, 1-3 blocks, no context
+    gate, inference."""
+    from .fused import _is_relu
+    from . import autograd
+    if context is not None or net.context_features:
+        return False
+    if any(not _is_relu(b.activation) for b in net.blocks):
+        return False
+    if autograd.needs_grad(first_in, *net.parameters()):
+        return False
+    return bool(_lib.lib().vcnf_resnet_trunk_supported(first_in.shape[1], net.hidden_features, len(net.blocks)))
+
+
+def pack_trunk(net):
+    from .fused_affine import _pack_chained
+    hb = net.hidden_features // 16
+    w0 = net.initial_layer.weight.detach()
+    parts = [_pack_chained(w0, hb, w0.shape[1] // 16), net.initial_layer.bias.detach()]
+    for blk in net.blocks:
+        for lin in blk.linear_layers:
+            parts += [_pack_chained(lin.weight.detach(), hb, hb), lin.bias.detach()]
+    return torch.cat([p.reshape(-1).float() for p in parts]).contiguous()
+
+
+def packed_trunk(coupling):
+    net = coupling.transform_net
+    params = [net.initial_layer.weight, net.initial_layer.bias] + [p for b in net.blocks for l in b.linear_layers
+                                                                   for p in (l.weight, l.bias)]
+    key = tuple((t.data_ptr(), t._version, str(t.device)) for t in params)
+    cache = coupling.__dict__.setdefault('_fused_trunk_pack', {})
+    if cache.get('key') != key:
+        cache['key'] = key
+        with torch.no_grad():
+            buf = pack_trunk(net)
+        old = cache.get('buf')
+        if old is not None and old.shape == buf.shape and old.device == buf.device:
+            old.copy_(buf)
+        else:
+            cache['buf'] = buf
+    return cache['buf']
+
+
 def run(coupling, inputs, context, sampling, log_q=None, sign=1.0):
     """Coupling layer with the conditioner trunk on PyTorch-ROCm and last layer + splines in one
     kernel; same (out, log_det) contract as PiecewiseRationalQuadraticCoupling._run."""
@@ -88,7 +131,11 @@ def run(coupling, inputs, context, sampling, log_q=None, sign=1.0):
     lad_i = None
     if uncond is not None and sampling:                 # coupling.py:110-114: the conditioner sees S^-1(x_id)
         xi, lad_i = uncond.inverse(xi)
-    h = net.hidden(xi if context is None else torch.cat((xi, context), dim=1), context)
+    first_in = xi if context is None else torch.cat((xi, context), dim=1)
+    if coupling.fused_trunk and trunk_eligible(net, first_in, context):
+        h = _lib.resnet_trunk(first_in, packed_trunk(coupling), net.hidden_features, len(net.blocks))
+    else:
+        h = net.hidden(first_in, context)
     if uncond is not None and not sampling:
         xi, lad_i = uncond.forward(xi)
     out = torch.empty_like(inputs)
