@@ -3,13 +3,14 @@
 cpu_baseline leg runs on the GPU box) next to the IMPORTED reference on the same C3 stack, same inputs, same thread
 count.  Build container only (needs /root/reference; the reference never travels).
 
-    PYTHONDONTWRITEBYTECODE=1 python profiles/tools/cpu_calibration.py > profiles/r02_cpu_baseline_calibration.txt
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/cpu_calibration.py > profiles/r02_cpu_baseline_calibration.txt
+(kept under tests/: it imports the oracle, which only tests/, smoke() and bench.py's cpu_baseline leg may do)
 """
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tests/golden -> repo root
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
 import numpy as np      # noqa: E402
 import torch            # noqa: E402
