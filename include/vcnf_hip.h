@@ -206,6 +206,23 @@ int vcnf_rqs_conditioner_input_f32(const float* x, int64_t batch, int32_t featur
                                    const vcnf_rqs_cfg* cfg, int apply_inverse_shared,
                                    float* out, void* stream);
 
+/* Identity half of one RQS coupling layer in one launch (coupling.py:76-116): for f < d_id and v = x[b, identity_idx[f]]
+ *   y = S_f(v) (inverse = 0) or S_f^-1(v) (inverse = 1) with the batch-shared unconditional spline of feature f
+ *       (PiecewiseRationalQuadraticCDF, coupling.py:165-246), or y = v when shared_w/h/d are all NULL;
+ *   out[b, identity_idx[f]] = y;   cond_in[b, f] = cond_sees_output ? y : v   (cond_in may be NULL): the conditioner
+ *       sees the raw identity features in the density direction (:78-80) and S^-1 of them when sampling (:110-114);
+ *   partial[c][b] = sum of log|dy/dv| over features 64 c .. 64 c + 63, c < vcnf_rqs_identity_half_partial_rows(d_id)
+ *       (written only with shared logits; the caller adds the rows - deterministic, no atomics).
+ * Bin counts 4, 8, 10, 16, 32; tails none / linear (vcnf_rqs_identity_half_supported).  Results are bitwise those of
+ * vcnf_rqs_shared_f32 on the gathered columns. */
+int vcnf_rqs_identity_half_supported(int32_t num_bins, int32_t tails);
+int64_t vcnf_rqs_identity_half_partial_rows(int32_t d_id);
+int vcnf_rqs_identity_half_f32(const float* x, float* y, float* cond_in, float* partial, int64_t batch,
+                               int32_t features, const int32_t* identity_idx, int32_t d_id,
+                               const float* shared_w, const float* shared_h, const float* shared_d,
+                               const vcnf_rqs_cfg* cfg, int inverse, int cond_sees_output,
+                               int32_t* bad_disc, void* stream);
+
 /* Packed conditioner weights of one fused RQS coupling layer: ONE device buffer of
  * vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim, num_blocks) floats (0: shape not supported) holding the ResidualNet's nn.Linear
  * weights (nets/resnet.py:78-90) re-ordered into matrix-core fragments, in the order

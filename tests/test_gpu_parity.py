@@ -852,7 +852,7 @@ def test_resnet_trunk_kernel_vs_torch(hip, d_in, blocks):
             p.normal_(0, 0.2)
     sd64 = {k[len("prqct.transform_net."):]: v.detach().double().cpu() for k, v in m.state_dict().items()
             if k.startswith("prqct.transform_net.")}
-    for b in (1, 17, 1024 + 5):
+    for b in (1, 17, 1024 + 5, 65536 + 21):          # the last one runs two 16-sample tiles per wave
         x = torch.randn(b, d_in, device="cuda")
         with torch.no_grad():
             assert fused_final.trunk_eligible(net, x, None)
@@ -866,6 +866,51 @@ def test_resnet_trunk_kernel_vs_torch(hip, d_in, blocks):
         scale = float(h64.abs().max())
         e_got, e_ref = float((got.double().cpu() - h64).abs().max()), float((ref32.double().cpu() - h64).abs().max())
         assert e_got <= 2.0 * e_ref + 1e-6 * scale, (d_in, b, e_got, e_ref)
+
+
+@pytest.mark.parametrize("k,tails,d,d_id", [(16, "linear", 1024, 512), (8, "linear", 37, 19), (10, "linear", 200, 70),
+                                            (4, None, 9, 4), (32, "linear", 130, 65)])
+def test_identity_half_kernel_bitwise(hip, k, tails, d, d_id):
+    """csrc/rqs_kernels.hip::rqs_identity_half_kernel (gather + batch-shared unconditional spline + conditioner input +
+    log-det partial rows in one launch, coupling.py:76-116) against the kernels it replaces on the gathered columns
+    (vcnf_rqs_shared_f32: same table build, same bin evaluation -> bitwise), ragged feature chunks and batches, both
+    directions, points outside the interval and exactly on its ends; and the plain gather without shared logits."""
+    g = torch.Generator().manual_seed(7 * k + d)
+    perm = torch.randperm(d, generator=g)[:d_id].sort().values
+    idx = perm.to(torch.int32).cuda()
+    nd = k - 1 if tails == "linear" else k + 1
+    sw, sh, sd_ = (torch.randn(d_id, n, generator=g).cuda() for n in (k, k, nd))
+    cfg = _lib.make_cfg(k, tails, tail_bound=3.0) if tails else _lib.make_cfg(k, None)
+    for b in (1, 63, 64 * 5 + 3):
+        if tails:
+            x = (torch.randn(b, d, generator=g) * 2.5).cuda()
+            x[0, perm[0]] = 3.0
+            x[-1, perm[-1]] = -3.0
+        else:
+            x = torch.rand(b, d, generator=g).cuda()
+        for inverse in (False, True):
+            rows = _lib.identity_half_rows(d_id, (sw, sh, sd_))
+            assert rows == (d_id + 63) // 64
+            partial = torch.full((rows + 1, b), float("nan"), device="cuda")
+            out = torch.full_like(x, float("nan"))
+            ci = _lib.rqs_identity_half(x, out, idx, d_id, (sw, sh, sd_), cfg, inverse, partial=partial[1:])
+            xi = x[:, perm.cuda()].contiguous()
+            y_ref, lad_ref = _lib.rqs_elementwise_shared(xi, sw, sh, sd_, cfg, inverse)
+            assert torch.equal(out[:, perm.cuda()], y_ref)
+            assert torch.equal(ci, y_ref if inverse else xi)
+            mask = torch.ones(d, dtype=torch.bool)
+            mask[perm] = False
+            assert torch.isnan(out[:, mask.cuda()]).all() and torch.isnan(partial[0]).all()   # nothing else is written
+            want = lad_ref.double().sum(1)
+            got = partial[1:].double().sum(0)
+            assert torch.allclose(got, want, rtol=1e-6, atol=1e-6 * d_id)
+            # rows are per 64-feature chunk
+            for c in range(rows):
+                assert torch.allclose(partial[1 + c].double(), lad_ref[:, 64 * c:64 * c + 64].double().sum(1), rtol=1e-6, atol=1e-5)
+        out = torch.full_like(x, float("nan"))
+        ci = _lib.rqs_identity_half(x, out, idx, d_id, None, None, False)
+        assert torch.equal(ci, x[:, perm.cuda()]) and torch.equal(out[:, perm.cuda()], ci)
+    assert nf.check_discriminant("cuda") is None
 
 
 def test_g21_c5_real_depth(hip):

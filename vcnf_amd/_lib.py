@@ -58,6 +58,10 @@ PROTOTYPES = {
                                ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P], _INT),
     "vcnf_rqs_conditioner_input_f32": ([_P, _I64, _I32, _P, _I32, _P, _I32, _P, _P, _P,
                                         ctypes.POINTER(RqsCfg), _INT, _P, _P], _INT),
+    "vcnf_rqs_identity_half_supported": ([_I32, _I32], _INT),
+    "vcnf_rqs_identity_half_partial_rows": ([_I32], _I64),
+    "vcnf_rqs_identity_half_f32": ([_P, _P, _P, _P, _I64, _I32, _P, _I32, _P, _P, _P, ctypes.POINTER(RqsCfg), _INT, _INT,
+                                    _P, _P], _INT),
     "vcnf_rqs_layer_fused_pack_floats": ([_I32, _I32, _I32, _I32], _I64),
     "vcnf_rqs_layer_fused_supported": ([_I32, _I32, _I32, _I32, _I32, _I32, _I32], _INT),
     "vcnf_rqs_layer_fused_f32": ([_P, _P, _P, _P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _I64,
@@ -500,16 +504,19 @@ def affine_coupling(z, param, t_off, d_t, scale_map, inverse, logdet=None, sign=
     return out, logdet
 
 
-def rqs_final_fused(x, h, out, tf_idx, d_t, hidden, wpack, cfg, inverse):
+def rqs_final_fused(x, h, out, tf_idx, d_t, hidden, wpack, cfg, inverse, partial=None):
     """Last conditioner layer + splines (csrc/fused_final.hip): writes out[:, tf_idx], returns the partial
-    log-det rows [rows, B]."""
+    log-det rows [rows, B] (written into the first rows of ``partial`` when the caller brings the buffer)."""
     dev = require_device(x, h, out, wpack)
     x, h = x.contiguous(), h.contiguous()
     if not out.is_contiguous():
         raise VcnfError("rqs_final_fused writes into a contiguous output tensor")
     b, d = x.shape
     rows = int(lib().vcnf_rqs_final_fused_partial_rows(d_t, cfg.num_bins))
-    partial = torch.empty(rows, b, dtype=torch.float32, device=dev)
+    if partial is None:
+        partial = torch.empty(rows, b, dtype=torch.float32, device=dev)
+    elif partial.shape[0] < rows or partial.shape[1] != b or not partial.is_contiguous():
+        raise VcnfError("partial log-det buffer %s too small for %d rows of %d" % (tuple(partial.shape), rows, b))
     with torch.cuda.device(dev), _timed("rqs_final_fused"):
         st = lib().vcnf_rqs_final_fused_f32(_ptr(x), _ptr(h), _ptr(out), _ptr(partial), b, d, _ptr(tf_idx), int(d_t),
                                             int(hidden), _ptr(wpack), wpack.numel(), ctypes.byref(cfg),
@@ -517,6 +524,39 @@ def rqs_final_fused(x, h, out, tf_idx, d_t, hidden, wpack, cfg, inverse):
                                             _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
     _check(st, "vcnf_rqs_final_fused_f32")
     return partial
+
+
+def identity_half_rows(d_id, shared):
+    return int(lib().vcnf_rqs_identity_half_partial_rows(d_id)) if shared is not None else 0
+
+
+def rqs_identity_half(x, out, id_idx, d_id, shared, cfg, inverse, partial=None, want_cond_in=True):
+    """Identity features of a coupling layer in one launch (csrc/rqs_kernels.hip::rqs_identity_half_kernel):
+    out[:, id_idx] = S(x[:, id_idx]) (S^-1 when ``inverse``; the plain copy without ``shared`` logits), the
+    conditioner's input rows [B, d_id] (raw columns in the density direction, S^-1 of them when sampling) and the
+    log-det partial rows, written into ``partial`` (rows identity_half_rows(d_id, shared))."""
+    dev = require_device(x, out, id_idx, *(shared or ()))
+    x = x.contiguous()
+    if not out.is_contiguous():
+        raise VcnfError("rqs_identity_half writes into a contiguous output tensor")
+    b, d = x.shape
+    cond_in = torch.empty(b, d_id, dtype=torch.float32, device=dev) if want_cond_in else None
+    if shared is not None:
+        sw, sh, sd = (t.detach().contiguous() for t in shared)
+        if partial is None or partial.shape[0] < identity_half_rows(d_id, shared) or partial.shape[1] != b:
+            raise VcnfError("rqs_identity_half needs a [rows, B] partial log-det buffer")
+    else:
+        sw = sh = sd = None
+    with torch.cuda.device(dev), _timed("rqs_identity_half"):
+        st = lib().vcnf_rqs_identity_half_f32(
+            _ptr(x), _ptr(out), _ptr(cond_in) if cond_in is not None else None,
+            _ptr(partial) if partial is not None else None, b, d, _ptr(id_idx), int(d_id),
+            _ptr(sw) if sw is not None else None, _ptr(sh) if sh is not None else None,
+            _ptr(sd) if sd is not None and sd.numel() else None,
+            ctypes.byref(cfg) if cfg is not None else None, int(bool(inverse)), int(bool(inverse)),
+            _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
+    _check(st, "vcnf_rqs_identity_half_f32")
+    return cond_in
 
 
 def resnet_trunk(x, wpack, hidden, num_blocks):

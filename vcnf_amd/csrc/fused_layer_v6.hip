@@ -564,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6_kernel(const FusedA
           float lg[P];
 #pragma unroll
           for (int tl = 0; tl < P; ++tl) lg[tl] = pa[(24 * f2 + tl) >> 4][(24 * f2 + tl) & 15];
-          rqs_lean_eval<INV>(xin[f2], lg, lc, yv[f2], lad[f2], bad);
+          rqs_lean_eval<8, INV>(xin[f2], lg, lc, yv[f2], lad[f2], bad);
         }
         *px[0] = yv[0];
         *px[1] = yv[1];

@@ -34,7 +34,10 @@ constexpr int kTrunkBlock = 256;     // 4 waves x 16 samples
 constexpr int kTH = 128, kTNB = kTH / 16;
 
 // packed floats: W0 [8][d_in/16][64][4] | b0 [128] | per block: Wa [8][8][64][4] | ba [128] | Wb [8][8][64][4] | bb [128]
-template <int NBLK>
+// NT: 16-sample column tiles per wave.  Every weight fragment is a 1 KB load per wave for 4 NT matrix instructions;
+// with one tile the four waves of a CU ask the vector cache for ~128 B per clock, twice what it delivers, so large
+// batches run two tiles per wave (same fragment, two accumulator sets).
+template <int NBLK, int NT>
 __global__ __launch_bounds__(kTrunkBlock) void resnet_trunk_kernel(const TrunkArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -49,77 +52,117 @@ __global__ __launch_bounds__(kTrunkBlock) void resnet_trunk_kernel(const TrunkAr
   const int off_b0 = kTNB * J * 256;
   const int off_blk = off_b0 + kTH;
   constexpr int kBlkFloats = 2 * (kTNB * kTNB * 256 + kTH);
-  const long long nwt = (a.B + 15) / 16;
+  constexpr int TS = 16 * NT;                    // samples per wave tile
+  const long long nwt = (a.B + TS - 1) / TS;
   const long long wstride = (long long)gridDim.x * (kTrunkBlock / 64);
   for (long long wt = (long long)blockIdx.x * (kTrunkBlock / 64) + wave; wt < nwt; wt += wstride) {
-    const long long b0 = wt * 16;
+    const long long b0 = wt * TS;
     const long long left = a.B - b0;
     // rows of this tile through a bounds-checked descriptor: rows past the batch read 0
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.x) + b0 * a.d_in, 0, (int)(min(left, 16LL) * a.d_in * 4), 0x00020000);
+        const_cast<float*>(a.x) + b0 * a.d_in, 0, (int)(min(left, (long long)TS) * a.d_in * 4), 0x00020000);
     // ---- first layer
-    floatx4 h[kTNB];
+    floatx4 h[NT][kTNB];
 #pragma unroll
-    for (int nb = 0; nb < kTNB; ++nb) h[nb] = wload(wr, qoff, 4 * (off_b0 + 16 * nb));
-    floatx4 xv = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(xr, (m16 * a.d_in + 4 * q) * 4, 0, 0));
+    for (int nb = 0; nb < kTNB; ++nb) {
+      const floatx4 b = wload(wr, qoff, 4 * (off_b0 + 16 * nb));
+#pragma unroll
+      for (int c = 0; c < NT; ++c) h[c][nb] = b;
+    }
+    floatx4 xv[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+      xv[c] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(xr, ((16 * c + m16) * a.d_in + 4 * q) * 4, 0, 0));
     for (int j = 0; j < J; ++j) {
-      const floatx4 xc = xv;
-      if (j + 1 < J)
-        xv = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(xr, (m16 * a.d_in + 16 * (j + 1) + 4 * q) * 4, 0, 0));
+      floatx4 xc[NT];
+#pragma unroll
+      for (int c = 0; c < NT; ++c) xc[c] = xv[c];
+      if (j + 1 < J) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+          xv[c] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  xr, ((16 * c + m16) * a.d_in + 16 * (j + 1) + 4 * q) * 4, 0, 0));
+      }
 #pragma unroll
       for (int nb = 0; nb < kTNB; ++nb) {
         const floatx4 w = wload(wr, voff, 4 * ((nb * J + j) * 256));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[nb] = mfma4(w[r], xc[r], h[nb]);
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < NT; ++c) h[c][nb] = mfma4(w[r], xc[c][r], h[c][nb]);
       }
     }
     // ---- residual blocks
 #pragma unroll
     for (int blk = 0; blk < NBLK; ++blk) {
       const int base = off_blk + blk * kBlkFloats;
-      floatx4 t[kTNB], u[kTNB];
+      floatx4 t[NT][kTNB];
 #pragma unroll
       for (int nb = 0; nb < kTNB; ++nb) {
-        floatx4 acc = wload(wr, qoff, 4 * (base + kTNB * kTNB * 256 + 16 * nb));
+        const floatx4 b = wload(wr, qoff, 4 * (base + kTNB * kTNB * 256 + 16 * nb));
+        floatx4 acc[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = b;
 #pragma unroll
         for (int pb = 0; pb < kTNB; ++pb) {
           const floatx4 w = wload(wr, voff, 4 * (base + (nb * kTNB + pb) * 256));
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc = mfma4(w[r], fmaxf(h[pb][r], 0.f), acc);
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = mfma4(w[r], fmaxf(h[c][pb][r], 0.f), acc[c]);
         }
-        t[nb] = acc;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) t[c][nb] = acc[c];
       }
       const int base2 = base + kTNB * kTNB * 256 + kTH;
+      floatx4 u[NT][kTNB];
 #pragma unroll
       for (int nb = 0; nb < kTNB; ++nb) {
-        floatx4 acc = wload(wr, qoff, 4 * (base2 + kTNB * kTNB * 256 + 16 * nb));
+        const floatx4 b = wload(wr, qoff, 4 * (base2 + kTNB * kTNB * 256 + 16 * nb));
+        floatx4 acc[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] = b;
 #pragma unroll
         for (int pb = 0; pb < kTNB; ++pb) {
           const floatx4 w = wload(wr, voff, 4 * (base2 + (nb * kTNB + pb) * 256));
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc = mfma4(w[r], fmaxf(t[pb][r], 0.f), acc);
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = mfma4(w[r], fmaxf(t[c][pb][r], 0.f), acc[c]);
         }
-        u[nb] = acc;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) u[c][nb] = acc[c];
       }
 #pragma unroll
-      for (int nb = 0; nb < kTNB; ++nb) h[nb] += u[nb];
-    }
-    // ---- out: lane holds units 16 nb + 4 q .. + 3 of sample m16
-    if (m16 < left) {
-      float* dst = a.h + (b0 + m16) * kTH + 4 * q;
+      for (int c = 0; c < NT; ++c)
 #pragma unroll
-      for (int nb = 0; nb < kTNB; ++nb) *reinterpret_cast<floatx4*>(dst + 16 * nb) = h[nb];
+        for (int nb = 0; nb < kTNB; ++nb) h[c][nb] += u[c][nb];
+    }
+    // ---- out: lane holds units 16 nb + 4 q .. + 3 of sample 16 c + m16
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      if (16 * c + m16 < left) {
+        float* dst = a.h + (b0 + 16 * c + m16) * kTH + 4 * q;
+#pragma unroll
+        for (int nb = 0; nb < kTNB; ++nb) *reinterpret_cast<floatx4*>(dst + 16 * nb) = h[c][nb];
+      }
     }
   }
 }
 
-template <int NBLK>
-static int launch_trunk(const TrunkArgs& a, hipStream_t st) {
-  const long long ntiles = (a.B + 63) / 64;
+template <int NBLK, int NT>
+static int launch_trunk_nt(const TrunkArgs& a, hipStream_t st) {
+  const long long ntiles = (a.B + 64 * NT - 1) / (64 * NT);
   const long long cap = 256 * 8;
   dim3 grid((unsigned)(ntiles < cap ? ntiles : cap));
-  hipLaunchKernelGGL((resnet_trunk_kernel<NBLK>), grid, dim3(kTrunkBlock), 0, st, a);
+  hipLaunchKernelGGL((resnet_trunk_kernel<NBLK, NT>), grid, dim3(kTrunkBlock), 0, st, a);
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
+}
+
+// two tiles per wave once that still gives every SIMD of the chip a wave (256 CUs x 4 waves x 32 samples)
+template <int NBLK>
+static int launch_trunk(const TrunkArgs& a, hipStream_t st) {
+  return a.B >= 2 * 256 * 4 * 32 ? launch_trunk_nt<NBLK, 2>(a, st) : launch_trunk_nt<NBLK, 1>(a, st);
 }
 
 }  // namespace vcnf

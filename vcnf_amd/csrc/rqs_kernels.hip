@@ -467,6 +467,123 @@ __global__ __launch_bounds__(kBlock) void rqs_conditioner_input_kernel(const Con
 }
 
 // ------------------------------------------------------------------ host side
+// ------------------------------------------------------------------ identity half of a coupling
+// Everything a coupling layer does with its identity features, in one launch (callers: the last-layer kernel's host
+// path, vcnf_amd/fused_final.py; reference coupling.py:76-116):
+//     v        = x[b, id_idx[f]]
+//     y        = S(v) / S^-1(v)  with the batch-shared spline of feature f (apply), or v
+//     out[b, id_idx[f]] = y ;  cond_in[b, f] = sampling ? y : v ;  partial[chunk][b] = sum over the chunk's features
+// It replaces a gather, the table build, the table evaluation (21 scattered global reads per element: 83 us for
+// the 16384 x 512 identity half of a config-C5 layer) and an index_put.  A workgroup owns a chunk of 64 features and
+// 128 rows: waves 0-2 build the chunk's knot tables into LDS, one COLUMN per feature ([entry][64]), so that with
+// lane = feature every table read of a wave is conflict free; each wave then walks 32 rows.  The bin is found
+// by bisection on the knots (they ascend, so the result is the count of knots <= x that rqs_point_table computes).
+struct IdHalfArgs {
+  const float* x;
+  float *y, *cond_in, *partial;
+  const int32_t* id_idx;
+  const float *sw, *sh, *sd;
+  int32_t* bad;
+  long long B;
+  int D, d_id, chunks, nd, apply, cond_out;
+  RqsConst c;
+};
+
+constexpr int kIdRows = 128;     // rows per workgroup (32 per wave)
+
+template <int K, bool INV>
+__global__ __launch_bounds__(kBlock) void rqs_identity_half_kernel(const IdHalfArgs a) {
+  __shared__ float tabT[3 * (K + 1) * 64];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int fc = blockIdx.x % a.chunks;
+  const long long rb = blockIdx.x / a.chunks;
+  const int f = fc * 64 + lane;
+  const bool fok = f < a.d_id;
+  const RqsConst& c = a.c;
+  if (a.apply) {
+    if (wave < 3 && fok) {                       // wave 0: x knots, 1: y knots, 2: derivatives
+      SplitLogits p{a.sw + (long long)f * K, a.sh + (long long)f * K, a.sd + (long long)f * a.nd,
+                    K, c.wh_scale, c.edge_logit, c.tails};
+      rqs_build_table_part(p, c, tabT + lane, 64, wave);
+    }
+    __syncthreads();
+  }
+  const int col = fok ? a.id_idx[f] : 0;
+  const float* t = tabT + lane;
+  const float* key = t + (INV ? (K + 1) * 64 : 0);
+  bool bad = false;
+  const long long r0 = rb * kIdRows + wave * (kIdRows / 4);
+  constexpr int U = 4;
+#pragma unroll 1
+  for (int i = 0; i < kIdRows / 4; i += U) {
+    float v[U], yv[U], lad[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long row = r0 + i + u;
+      v[u] = (fok && row < a.B) ? a.x[row * a.D + col] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      yv[u] = v[u];
+      lad[u] = 0.f;
+      if (a.apply) {
+        const bool inside = c.tails == 0 || ((v[u] >= c.lo_x) && (v[u] <= c.hi_x));
+        const float xi = inside ? v[u] : c.lo_x;
+        int bin = 0;
+        if constexpr ((K & (K - 1)) == 0) {
+#pragma unroll
+          for (int step = K / 2; step >= 1; step >>= 1) bin += (xi >= key[(bin + step) * 64]) ? step : 0;
+        } else {
+#pragma unroll
+          for (int k = 1; k < K; ++k) bin += (xi >= key[k * 64]) ? 1 : 0;
+        }
+        RqsBin b;
+        b.xl = t[bin * 64];
+        b.w = t[(bin + 1) * 64] - b.xl;
+        b.yl = t[(K + 1 + bin) * 64];
+        b.h = t[(K + 2 + bin) * 64] - b.yl;
+        b.d0 = t[(2 * K + 2 + bin) * 64];
+        b.d1 = t[(2 * K + 3 + bin) * 64];
+        float yy, ll;
+        bool bb = false;
+        rqs_bin_eval<INV>(xi, b, yy, ll, bb);
+        yv[u] = inside ? yy : v[u];
+        lad[u] = (inside && fok) ? ll : 0.f;
+        bad = bad || (inside && fok && bb);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long row = r0 + i + u;
+      if (fok && row < a.B) {
+        a.y[row * a.D + col] = yv[u];
+        if (a.cond_in) a.cond_in[row * a.d_id + f] = a.cond_out ? yv[u] : v[u];
+      }
+      if (a.apply) {
+        float s = lad[u];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m, 64);
+        if (lane == 0 && row < a.B) a.partial[(long long)fc * a.B + row] = s;
+      }
+    }
+  }
+  if (INV && a.bad && bad) atomicAdd(a.bad, 1);
+}
+
+template <bool INV>
+static bool launch_identity_half(const IdHalfArgs& a, dim3 grid, hipStream_t st) {
+  switch (a.c.K) {
+    case 4: hipLaunchKernelGGL((rqs_identity_half_kernel<4, INV>), grid, dim3(kBlock), 0, st, a); return true;
+    case 8: hipLaunchKernelGGL((rqs_identity_half_kernel<8, INV>), grid, dim3(kBlock), 0, st, a); return true;
+    case 10: hipLaunchKernelGGL((rqs_identity_half_kernel<10, INV>), grid, dim3(kBlock), 0, st, a); return true;
+    case 16: hipLaunchKernelGGL((rqs_identity_half_kernel<16, INV>), grid, dim3(kBlock), 0, st, a); return true;
+    case 32: hipLaunchKernelGGL((rqs_identity_half_kernel<32, INV>), grid, dim3(kBlock), 0, st, a); return true;
+    default: return false;
+  }
+}
+
 static int fill_const(const vcnf_rqs_cfg* cfg, RqsConst& c, int& n_deriv) {
   if (!cfg) return VCNF_ERR_NULL;
   const int K = cfg->num_bins;
@@ -702,6 +819,47 @@ extern "C" int vcnf_rqs_shared_f32(const float* x, const float* sw, const float*
   dim3 grid((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16));
   if (inverse) launch_table_eval<true>(a, grid, st);
   else launch_table_eval<false>(a, grid, st);
+  return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
+}
+
+extern "C" int vcnf_rqs_identity_half_supported(int32_t num_bins, int32_t tails) {
+  return ((num_bins == 4 || num_bins == 8 || num_bins == 10 || num_bins == 16 || num_bins == 32) &&
+          (tails == VCNF_TAILS_NONE || tails == VCNF_TAILS_LINEAR)) ? 1 : 0;
+}
+
+extern "C" int64_t vcnf_rqs_identity_half_partial_rows(int32_t d_id) { return d_id > 0 ? (d_id + 63) / 64 : 0; }
+
+extern "C" int vcnf_rqs_identity_half_f32(const float* x, float* y, float* cond_in, float* partial, int64_t batch,
+                                          int32_t features, const int32_t* identity_idx, int32_t d_id,
+                                          const float* shared_w, const float* shared_h, const float* shared_d,
+                                          const vcnf_rqs_cfg* cfg, int inverse, int cond_sees_output,
+                                          int32_t* bad_disc, void* stream) {
+  IdHalfArgs a;
+  const bool any_sh = shared_w || shared_h || shared_d;
+  a.nd = 0;
+  if (any_sh) {
+    const int rc = fill_const(cfg, a.c, a.nd);
+    if (rc != VCNF_OK) return rc;
+    if (!vcnf_rqs_identity_half_supported(a.c.K, a.c.tails)) return VCNF_ERR_UNSUPPORTED;
+    if (!(shared_w && shared_h) || (a.nd > 0 && !shared_d)) return VCNF_ERR_NULL;
+  } else {
+    a.c = RqsConst{};
+    a.c.K = 4;
+  }
+  if (batch < 0 || features < 1 || d_id < 0 || d_id > features) return VCNF_ERR_SHAPE;
+  if (batch == 0 || d_id == 0) return VCNF_OK;
+  if (!x || !y || !identity_idx || (any_sh && !partial)) return VCNF_ERR_NULL;
+  a.x = x; a.y = y; a.cond_in = cond_in; a.partial = partial; a.id_idx = identity_idx;
+  a.sw = shared_w; a.sh = shared_h; a.sd = shared_d; a.bad = bad_disc;
+  a.B = batch; a.D = features; a.d_id = d_id; a.chunks = (d_id + 63) / 64;
+  a.apply = any_sh ? 1 : 0;
+  a.cond_out = cond_sees_output ? 1 : 0;
+  const long long rblocks = (batch + kIdRows - 1) / kIdRows;
+  if (rblocks * a.chunks > 0x7fffffffLL) return VCNF_ERR_SHAPE;
+  dim3 grid((unsigned)(rblocks * a.chunks));
+  hipStream_t st = (hipStream_t)stream;
+  const bool ok = inverse ? launch_identity_half<true>(a, grid, st) : launch_identity_half<false>(a, grid, st);
+  if (!ok) return VCNF_ERR_UNSUPPORTED;
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }
 

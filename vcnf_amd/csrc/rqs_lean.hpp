@@ -53,24 +53,27 @@ __device__ __forceinline__ float lean_derivative(float v2, float min_d) {
   return min_d + fmaf(kLn2, fmaxf(v2, 0.f) + l2, cc);
 }
 
-// lg: 8 width logits, 8 height logits, 7 derivative logits (pre-scaled, see above); linear tails: a point
+// lg: K width logits, K height logits, K - 1 derivative logits (pre-scaled, see above); linear tails: a point
 // outside [lo, hi] maps to itself with log|det| 0 (evaluated at the left end, selected away afterwards).
-template <bool INV>
-__device__ __forceinline__ void rqs_lean_eval(float x, const float (&lg)[23], const LeanConst& lc,
+template <int K, bool INV>
+__device__ __forceinline__ void rqs_lean_eval(float x, const float (&lg)[3 * K - 1], const LeanConst& lc,
                                               float& yv, float& lad, bool& bad) {
-  constexpr int K = 8;
+  static_assert(K >= 4 && K % 2 == 0, "bin count");
   const bool inside = (x >= lc.lo_x) && (x <= lc.hi_x);
   const float xi = inside ? x : lc.lo_x;
   float ew[K], eh[K];
   {
-    float mw = fmaxf(fmaxf(lg[0], lg[1]), lg[2]), mh = fmaxf(fmaxf(lg[8], lg[9]), lg[10]);
-    mw = fmaxf(fmaxf(mw, lg[3]), lg[4]); mh = fmaxf(fmaxf(mh, lg[11]), lg[12]);
-    mw = fmaxf(fmaxf(mw, lg[5]), lg[6]); mh = fmaxf(fmaxf(mh, lg[13]), lg[14]);
-    mw = fmaxf(mw, lg[7]); mh = fmaxf(mh, lg[15]);
+    float mw = fmaxf(fmaxf(lg[0], lg[1]), lg[2]), mh = fmaxf(fmaxf(lg[K], lg[K + 1]), lg[K + 2]);   // v_max3_f32
+#pragma unroll
+    for (int k = 3; k + 1 < K; k += 2) {
+      mw = fmaxf(fmaxf(mw, lg[k]), lg[k + 1]);
+      mh = fmaxf(fmaxf(mh, lg[K + k]), lg[K + k + 1]);
+    }
+    mw = fmaxf(mw, lg[K - 1]); mh = fmaxf(mh, lg[2 * K - 1]);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       ew[k] = __builtin_amdgcn_exp2f(lg[k] - mw);
-      eh[k] = __builtin_amdgcn_exp2f(lg[8 + k] - mh);
+      eh[k] = __builtin_amdgcn_exp2f(lg[K + k] - mh);
     }
   }
   float cw[K], ch[K];                       // prefix sums of the softmax numerators
@@ -86,7 +89,7 @@ __device__ __forceinline__ void rqs_lean_eval(float x, const float (&lg)[23], co
   const float Sa = INV ? Sh : Sw, Sb = INV ? Sw : Sh;
   const float u = (xi - (INV ? lc.lo_y : lc.lo_x)) * (Sa * (INV ? lc.ky : lc.kx));
   float selca = 0.f, selea = ea[0], selcb = 0.f, seleb = eb[0];
-  float d0 = lc.edge2, d1 = lg[16];
+  float d0 = lc.edge2, d1 = lg[2 * K];
 #pragma unroll
   for (int k = 1; k < K; ++k) {             // searchsorted (splines.py:12-17): last left edge that is <= u
     const float ca_l = fmaf((float)k, mSa, ca[k - 1]);
@@ -96,8 +99,8 @@ __device__ __forceinline__ void rqs_lean_eval(float x, const float (&lg)[23], co
     selea = take ? ea[k] : selea;
     selcb = take ? cb_l : selcb;
     seleb = take ? eb[k] : seleb;
-    d0 = take ? lg[16 + k - 1] : d0;
-    d1 = take ? (k == K - 1 ? lc.edge2 : lg[16 + k]) : d1;
+    d0 = take ? lg[2 * K + k - 1] : d0;
+    d1 = take ? (k == K - 1 ? lc.edge2 : lg[2 * K + k]) : d1;
   }
   const float wa = selea + mSa, wb = seleb + mSb;      // bin extents in exp-sum units
   const float D0 = lean_derivative(d0, lc.min_d), D1 = lean_derivative(d1, lc.min_d);

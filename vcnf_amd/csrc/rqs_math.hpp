@@ -288,35 +288,37 @@ struct StridedLogits {
 // Per-feature knot table for batch-shared logits (PiecewiseRationalQuadraticCDF,
 // coupling.py:165-246): xk[K+1] | yk[K+1] | dk[K+1], built once per workgroup with
 // the same arithmetic as rqs_select, so table and direct evaluation agree bitwise.
+// `stride`: distance in floats between consecutive table entries (1 = the row layout above; 64 = one
+// LDS column per feature of a 64-feature chunk, rqs_identity_half_kernel).  The three columns are independent of each
+// other: rqs_build_table_part builds one (0 x knots, 1 y knots, 2 derivatives), so three waves can share a table.
 template <class P>
-__device__ __forceinline__ void rqs_build_table(const P& p, const RqsConst& c, float* tab) {
+__device__ __forceinline__ void rqs_build_table_part(const P& p, const RqsConst& c, float* tab, int stride, int part) {
   const int K = c.K;
-  float mw = -INFINITY, mh = -INFINITY;
-  for (int k = 0; k < K; ++k) {
-    mw = fmaxf(mw, p.w(k));
-    mh = fmaxf(mh, p.h(k));
+  float* col = tab + part * (K + 1) * stride;
+  if (part == 2) {
+    for (int k = 0; k <= K; ++k) col[k * stride] = c.min_d + softplus_f(p.d(k));
+    return;
   }
+  const bool xs = part == 0;
+  float m = -INFINITY;
+  for (int k = 0; k < K; ++k) m = fmaxf(m, xs ? p.w(k) : p.h(k));
   const float sc2 = p.scale * kLog2e;
-  float sw = 0.f, sh = 0.f;
+  float sum = 0.f;
+  for (int k = 0; k < K; ++k) sum += hw_exp2(((xs ? p.w(k) : p.h(k)) - m) * sc2);
+  const float g = div_nr(xs ? c.free_w : c.free_h, sum);
+  const float mn = xs ? c.min_w : c.min_h, span = xs ? c.span_x : c.span_y, lo = xs ? c.lo_x : c.lo_y;
+  float cum = 0.f;
+  col[0] = lo;
   for (int k = 0; k < K; ++k) {
-    sw += hw_exp2((p.w(k) - mw) * sc2);
-    sh += hw_exp2((p.h(k) - mh) * sc2);
+    cum += fmaf(hw_exp2(((xs ? p.w(k) : p.h(k)) - m) * sc2), g, mn);
+    col[(k + 1) * stride] = (k == K - 1) ? (xs ? c.hi_x : c.hi_y) : fmaf(span, cum, lo);
   }
-  const float gw = div_nr(c.free_w, sw), gh = div_nr(c.free_h, sh);
-  float cw = 0.f, ch = 0.f;
-  float* xk = tab;
-  float* yk = tab + (K + 1);
-  float* dk = tab + 2 * (K + 1);
-  xk[0] = c.lo_x;
-  yk[0] = c.lo_y;
-  dk[0] = c.min_d + softplus_f(p.d(0));
-  for (int k = 0; k < K; ++k) {
-    cw += fmaf(hw_exp2((p.w(k) - mw) * sc2), gw, c.min_w);
-    ch += fmaf(hw_exp2((p.h(k) - mh) * sc2), gh, c.min_h);
-    xk[k + 1] = (k == K - 1) ? c.hi_x : fmaf(c.span_x, cw, c.lo_x);
-    yk[k + 1] = (k == K - 1) ? c.hi_y : fmaf(c.span_y, ch, c.lo_y);
-    dk[k + 1] = c.min_d + softplus_f(p.d(k + 1));
-  }
+}
+
+template <class P>
+__device__ __forceinline__ void rqs_build_table(const P& p, const RqsConst& c, float* tab, int stride = 1) {
+#pragma unroll 1
+  for (int part = 0; part < 3; ++part) rqs_build_table_part(p, c, tab, stride, part);
 }
 
 // KT > 0: bin count known at compile time (the knot scan unrolls and its LDS reads batch).

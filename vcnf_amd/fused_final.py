@@ -5,7 +5,8 @@ Packed buffer (floats): for feature group g (features 4 g .. 4 g + 3), row block
 fragments hi | lo of 64 lanes x 8 halves, lane = 16 q' + i holding
     W[(4 g + (i >> 2)) * P + 4 b + (i & 3)][32 s + 8 q' + j],  j = 0..7      (natural k order: the
 operand comes from memory, not from a previous layer's accumulators), rows with 4 b + (i & 3) >= P or
-feature >= d_t zero; then the bias rows [g][q][4 P4] in accumulator order.
+feature >= d_t zero; then the bias rows [g][q][4 P4] in accumulator order.  Weights and biases carry the logit
+scale and the log2(e) factors of the spline's exponentials (see pack).
 """
 import torch
 
@@ -30,8 +31,14 @@ def eligible(coupling, inputs, context):
                                                           coupling.num_bins, code))
 
 
-def pack(weight, bias, d_t, k):
+def pack(weight, bias, d_t, k, wh_scale):
+    """Scaled like fused._pack_final6 (csrc/rqs_lean.hpp evaluates 2^x on pre-scaled logits): width / height rows by
+    wh_scale * log2(e) (coupling.py:314-316), derivative rows by log2(e)."""
+    from .fused import LOG2E
     p = 3 * k - 1
+    scale = torch.where(torch.arange(p, device=weight.device) < 2 * k, wh_scale * LOG2E, LOG2E).double().repeat(d_t)
+    weight = (weight.double() * scale.view(-1, 1)).float()
+    bias = (bias.double() * scale).float()
     p4 = (p + 3) // 4
     ng = (d_t + 3) // 4
     hdim = weight.shape[1]
@@ -67,7 +74,8 @@ def packed_weights(coupling):
     if cache.get('key') != key:
         cache['key'] = key
         with torch.no_grad():
-            buf = pack(lin.weight.detach(), lin.bias.detach(), coupling.num_transform_features, coupling.num_bins)
+            buf = pack(lin.weight.detach(), lin.bias.detach(), coupling.num_transform_features, coupling.num_bins,
+                       float(coupling._cfg(True).wh_scale))
         old = cache.get('buf')
         if old is not None and old.shape == buf.shape and old.device == buf.device:
             old.copy_(buf)
@@ -122,26 +130,50 @@ def packed_trunk(coupling):
     return cache['buf']
 
 
+def _identity_kernel_ok(coupling):
+    """The identity features go through csrc/rqs_kernels.hip::rqs_identity_half_kernel: no unconditional spline, or one
+    with a single (tails, bound) for all features in a bin count that kernel is built for."""
+    uncond = coupling.unconditional_transform
+    if uncond is None:
+        return True
+    if uncond.per_feature or uncond.tails not in ('linear', None):
+        return False
+    code = _lib.TAILS_LINEAR if uncond.tails == 'linear' else _lib.TAILS_NONE
+    return bool(_lib.lib().vcnf_rqs_identity_half_supported(uncond.num_bins, code))
+
+
 def run(coupling, inputs, context, sampling, log_q=None, sign=1.0):
-    """Coupling layer with the conditioner trunk on PyTorch-ROCm and last layer + splines in one
-    kernel; same (out, log_det) contract as PiecewiseRationalQuadraticCoupling._run."""
+    """Coupling layer in three launches: identity half (gather, unconditional spline, conditioner input), conditioner
+    trunk (csrc/resnet_trunk.hip, or PyTorch-ROCm for shapes it does not cover), last layer + splines
+    (csrc/fused_final.hip); same (out, log_det) contract as PiecewiseRationalQuadraticCoupling._run."""
     net = coupling.transform_net
     uncond = coupling.unconditional_transform
-    xi = inputs[:, coupling.identity_features]
+    d_t, k = coupling.num_transform_features, coupling.num_bins
+    out = torch.empty_like(inputs)
     lad_i = None
-    if uncond is not None and sampling:                 # coupling.py:110-114: the conditioner sees S^-1(x_id)
-        xi, lad_i = uncond.inverse(xi)
+    if _identity_kernel_ok(coupling):
+        shared = uncond.logits() if uncond is not None else None
+        rows_f = int(_lib.lib().vcnf_rqs_final_fused_partial_rows(d_t, k))
+        rows_i = _lib.identity_half_rows(coupling.num_identity_features, shared)
+        partial = torch.empty(rows_f + rows_i, inputs.shape[0], dtype=torch.float32, device=inputs.device)
+        xi = _lib.rqs_identity_half(inputs, out, coupling._index32('id'), coupling.num_identity_features, shared,
+                                    uncond._cfg() if uncond is not None else None, sampling,
+                                    partial=partial[rows_f:] if rows_i else None)
+    else:
+        partial = None
+        xi = inputs[:, coupling.identity_features]
+        if sampling:                                    # coupling.py:110-114: the conditioner sees S^-1(x_id)
+            xi, lad_i = uncond.inverse(xi)
+            out[:, coupling.identity_features] = xi
+        else:
+            out[:, coupling.identity_features], lad_i = uncond.forward(xi)
     first_in = xi if context is None else torch.cat((xi, context), dim=1)
     if coupling.fused_trunk and trunk_eligible(net, first_in, context):
         h = _lib.resnet_trunk(first_in, packed_trunk(coupling), net.hidden_features, len(net.blocks))
     else:
         h = net.hidden(first_in, context)
-    if uncond is not None and not sampling:
-        xi, lad_i = uncond.forward(xi)
-    out = torch.empty_like(inputs)
-    out[:, coupling.identity_features] = xi
-    partial = _lib.rqs_final_fused(inputs, h, out, coupling._index32('tf'), coupling.num_transform_features,
-                                   net.hidden_features, packed_weights(coupling), coupling._cfg(True), sampling)
+    partial = _lib.rqs_final_fused(inputs, h, out, coupling._index32('tf'), d_t, net.hidden_features,
+                                   packed_weights(coupling), coupling._cfg(True), sampling, partial=partial)
     lad = partial.sum(0) if partial.shape[0] > 1 else partial[0]
     if lad_i is not None:
         lad = lad + lad_i
