@@ -206,6 +206,16 @@ int vcnf_rqs_conditioner_input_f32(const float* x, int64_t batch, int32_t featur
                                    const vcnf_rqs_cfg* cfg, int apply_inverse_shared,
                                    float* out, void* stream);
 
+/* Per-pixel channel mixing of an image batch: y[b, o, p] = sum_c matrix[o, c] x[b, c, p] + shift[o] for x, y
+ * [batch, channels, inner] (NCHW, inner = H W); matrix [channels, channels] row-major and shift [channels] on the device.
+ * One launch for Glow's invertible 1x1 convolution (flows/mixing.py:57-128) composed with the neighbouring ActNorm
+ * (flows/normalization.py:8-38, flows/affine/coupling.py:37-53); the caller composes matrix / shift from the layer
+ * parameters and adds the constant log|det| (vcnf_amd/flows/affine/glow.py).  Exact fp32 products on
+ * v_mfma_f32_16x16x4_f32.  channels: multiple of 4, 4..64 (vcnf_channel_mix_supported). */
+int vcnf_channel_mix_supported(int32_t channels);
+int vcnf_channel_mix_f32(const float* x, float* y, const float* matrix, const float* shift,
+                         int64_t batch, int32_t channels, int64_t inner, void* stream);
+
 /* Identity half of one RQS coupling layer in one launch (coupling.py:76-116): for f < d_id and v = x[b, identity_idx[f]]
  *   y = S_f(v) (inverse = 0) or S_f^-1(v) (inverse = 1) with the batch-shared unconditional spline of feature f
  *       (PiecewiseRationalQuadraticCDF, coupling.py:165-246), or y = v when shared_w/h/d are all NULL;

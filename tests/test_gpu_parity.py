@@ -839,6 +839,63 @@ def test_g20_c4_real_shape(hip):
         assert torch.isfinite(zb).all() and float(err.max()) <= 64.0 * float(ref_rt.max()) + 1e-5
 
 
+@pytest.mark.parametrize("c,h,w", [(48, 4, 4), (24, 8, 8), (12, 16, 16), (4, 3, 5), (64, 2, 2), (20, 1, 1)])
+def test_channel_mix_kernel(hip, c, h, w):
+    """csrc/channel_mix.hip: y[b, o, p] = sum_c M[o, c] x[b, c, p] + v[o] (invertible 1x1 convolution + ActNorm of a
+    GlowBlock in one pass, mixing.py:57-128 with normalization.py:8-38) against fp64, beside torch's own fp32 conv2d;
+    ragged pixel counts (tiles of 16 pixels cross image boundaries when H W is not a multiple of 16)."""
+    g = torch.Generator().manual_seed(c * 100 + h)
+    mat = torch.randn(c, c, generator=g).cuda()
+    vec = torch.randn(c, generator=g).cuda()
+    for b in (1, 3, 257):
+        x = torch.randn(b, c, h, w, generator=g).cuda()
+        got = _lib.channel_mix(x, mat, vec)
+        ref64 = torch.einsum("oc,bchw->bohw", mat.double(), x.double()) + vec.double().view(1, c, 1, 1)
+        ref32 = torch.nn.functional.conv2d(x, mat.view(c, c, 1, 1), vec)
+        scale = float(ref64.abs().max())
+        e_got, e_ref = float((got.double() - ref64).abs().max()), float((ref32.double() - ref64).abs().max())
+        assert got.shape == x.shape and e_got <= 2.0 * e_ref + 1e-6 * scale, (c, b, e_got, e_ref)
+    with pytest.raises(_lib.VcnfError):
+        _lib.channel_mix(torch.randn(2, 6, 2, 2, device="cuda"), torch.eye(6, device="cuda"), torch.zeros(6, device="cuda"))
+
+
+@pytest.mark.parametrize("use_lu", [True, False])
+def test_glow_block_fused_mixers_match_layerwise(hip, use_lu):
+    """GlowBlock with the 1x1 convolution and ActNorm composed into one channel map (vcnf_amd/flows/affine/glow.py)
+    against the same block evaluated layer by layer (conv2d + ActNorm kernel; glow.py:59-73), both directions, and
+    against the fp64 composition; then a parameter update through .data needs refresh_packed."""
+    torch.manual_seed(5 + use_lu)
+    blk = nf.flows.GlowBlock(24, 32, split_mode="channel", scale=True, use_lu=use_lu).cuda().eval()
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            if "param_map" in n:
+                p.normal_(0, 0.05)
+        x = torch.randn(37, 24, 8, 8, device="cuda")
+        blk.fused_mixers = False
+        blk(x)                                             # initialises the ActNorm from this batch
+        blk.flows[-1].s.add_(0.3 * torch.randn_like(blk.flows[-1].s))
+        blk.flows[-1].t.add_(0.3 * torch.randn_like(blk.flows[-1].t))
+        ref_f, ref_fl = blk(x)
+        ref_i, ref_il = blk.inverse(x)
+        blk.fused_mixers = True
+        assert blk._mixer_eligible(x)
+        got_f, got_fl = blk(x)
+        got_i, got_il = blk.inverse(x)
+        for got, ref in ((got_f, ref_f), (got_i, ref_i)):
+            assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+        assert_close(got_fl, ref_fl.cpu(), rtol=1e-6, atol=1e-4, what="log_det sampling direction")
+        assert_close(got_il, ref_il.cpu(), rtol=1e-6, atol=1e-4, what="log_det density direction")
+        back, bl = blk.inverse(got_f)
+        assert float((back - x).abs().max()) <= 1e-4 and float((bl + got_fl).abs().max()) <= 1e-3
+        # cached composition: a .data update is not seen until refresh_packed
+        blk.flows[-1].t.data.add_(1.0)
+        stale, _ = blk(x)
+        assert torch.equal(stale, got_f)
+        nf.refresh_packed(blk)
+        fresh, _ = blk(x)
+        assert float((fresh - got_f - 1.0).abs().max()) <= 1e-4
+
+
 @pytest.mark.parametrize("d_in,blocks", [(512, 2), (16, 1), (80, 3)])
 def test_resnet_trunk_kernel_vs_torch(hip, d_in, blocks):
     """csrc/resnet_trunk.hip (ResidualNet trunk in one launch, exact fp32 matrix instructions) against the module's own

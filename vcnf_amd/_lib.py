@@ -58,6 +58,8 @@ PROTOTYPES = {
                                ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P], _INT),
     "vcnf_rqs_conditioner_input_f32": ([_P, _I64, _I32, _P, _I32, _P, _I32, _P, _P, _P,
                                         ctypes.POINTER(RqsCfg), _INT, _P, _P], _INT),
+    "vcnf_channel_mix_supported": ([_I32], _INT),
+    "vcnf_channel_mix_f32": ([_P, _P, _P, _P, _I64, _I32, _I64, _P], _INT),
     "vcnf_rqs_identity_half_supported": ([_I32, _I32], _INT),
     "vcnf_rqs_identity_half_partial_rows": ([_I32], _I64),
     "vcnf_rqs_identity_half_f32": ([_P, _P, _P, _P, _I64, _I32, _P, _I32, _P, _P, _P, ctypes.POINTER(RqsCfg), _INT, _INT,
@@ -651,6 +653,24 @@ def affine_const(z, s, t, inverse):
         st = lib().vcnf_affine_const_f32(_ptr(z), _ptr(s), _ptr(t), _ptr(out), b, c, inner,
                                          int(bool(inverse)), _stream())
     _check(st, "vcnf_affine_const_f32")
+    return out
+
+
+def channel_mix(z, matrix, shift):
+    """y[b, o, ...] = sum_c matrix[o, c] z[b, c, ...] + shift[o] (csrc/channel_mix.hip): invertible 1x1 convolution
+    and ActNorm of a GlowBlock in one pass over the activations."""
+    dev = require_device(z, matrix, shift)
+    z = z.contiguous()
+    b, c = z.shape[0], z.shape[1]
+    if tuple(matrix.shape) != (c, c) or shift.numel() != c:
+        raise VcnfError("channel_mix: matrix %s / shift %s do not match %d channels" % (
+            tuple(matrix.shape), tuple(shift.shape), c))
+    inner = int(z[0, 0].numel()) if z.dim() > 2 else 1
+    out = torch.empty_like(z)
+    with torch.cuda.device(dev), _timed("channel_mix"):
+        st = lib().vcnf_channel_mix_f32(_ptr(z), _ptr(out), _ptr(matrix.contiguous()), _ptr(shift.contiguous()), b, c,
+                                        inner, _stream())
+    _check(st, "vcnf_channel_mix_f32")
     return out
 
 
