@@ -148,7 +148,7 @@ def cpu_baseline(model, budget_s=20.0):
 
 
 def bench_other(args, device, rank, world):
-    """BASELINE.json's configurations C2 and C5 (one line each, same schema; not the headline metric)."""
+    """BASELINE.json's configurations C2, C4 and C5 (one line each, same schema; not the headline metric)."""
     from vcnf_amd.sharded import max_over_ranks
     torch.manual_seed(0)
     if args.config == "C2":
@@ -164,6 +164,24 @@ def bench_other(args, device, rank, world):
         hbm_bytes = 4 * d * 2 + 8                                             # x once, y once, log_q
         workload = "C2: tabular D=32, 8 affine couplings (MLP 16-64-64-32) + swap permutations, batch=%d per GPU" % B
         dtype = "f32"
+    elif args.config == "C4":
+        d, layers, B = 3072, 48, 16384 if args.batch == 1 << 20 else args.batch
+        levels = [(48, 4, 4), (24, 8, 8), (12, 16, 16)]
+        q0, merges, flows = [], [], []
+        for i, shape in enumerate(levels):
+            fl = [nf.flows.GlowBlock(shape[0], 256, split_mode="channel", scale=True) for _ in range(16)]
+            flows += [fl + [nf.flows.Squeeze()]]
+            if i > 0:
+                merges += [nf.flows.Merge()]
+            q0 += [nf.distributions.DiagGaussian(shape if i == 0 else (shape[0] // 2,) + shape[1:])]
+        tag, kname = "channel_mix", "channel_mix_kernel"
+        bytes_sl = 8 * sum(c * h * w for c, h, w in levels) // 3              # average over the three levels' launches
+        work, peak, unit, bound = bytes_sl, HBM_PEAK, "GB/s", "hbm"
+        hbm_bytes = None
+        workload = ("C4: 3 x 32 x 32 images, multiscale Glow (3 levels x 16 GlowBlocks, 256 hidden channels), batch=%d per "
+                    "GPU; the conv conditioners are MIOpen calls (they dominate the step), affine couplings and the "
+                    "1x1 convolution + ActNorm mixers are this repository's kernels" % B)
+        dtype = "f32"
     else:
         d, layers, B = 1024, 24, 524288 if args.batch == 1 << 20 else args.batch
         flows = [nf.flows.CoupledRationalQuadraticSpline(d, 2, 128, 16, reverse_mask=bool(i % 2)) for i in range(layers)]
@@ -175,14 +193,25 @@ def bench_other(args, device, rank, world):
                     "(the per-GPU shard of the 4M batch is 524288; the conditioner logits never exist in memory, so the "
                     "shard is one pass)" % B)
         dtype = "f32 (last conditioner layer: fp16x3 split operands, fp32 accumulate; trunk fp32)"
-    model = nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows).to(device).eval()
+    if args.config == "C4":
+        model = nf.MultiscaleFlow(q0, flows, merges, class_cond=False).to(device).eval()
+    else:
+        model = nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows).to(device).eval()
     with torch.no_grad():
         for n, p in model.named_parameters():
             if "unnormalized_" in n:
                 p.normal_(0.0, 0.5)
+            if n.endswith("param_map.net.4.weight") or n.endswith("param_map.net.4.bias"):
+                p.normal_(0.0, 0.02)          # Glow's zero-initialised last convolution would make every coupling the identity
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
-    x = torch.randn(B, d, device=device, generator=gen)
-    eps = torch.randn(B, d, device=device, generator=gen)
+    if args.config == "C4":
+        x = torch.rand(B, 3, 32, 32, device=device, generator=gen)
+        eps = [torch.randn(B, *q.loc.shape[1:], device=device, generator=gen) for q in model.q0]
+        with torch.no_grad():
+            model.log_prob(x[:2048])          # the first batch initialises the ActNorms (normalization.py:22-27)
+    else:
+        x = torch.randn(B, d, device=device, generator=gen)
+        eps = torch.randn(B, d, device=device, generator=gen)
     evaluator = nf.ShardedEvaluator(model.log_prob)
 
     def step():
@@ -227,6 +256,9 @@ def bench_other(args, device, rank, world):
                             "note": ("algorithmic flop %d per sample-layer x %d layers per launch (MLP conditioners on "
                                      "v_mfma_f32_16x16x4_f32); HBM side of a launch: %d B per sample (%.1f us at 8 TB/s)"
                                      % (flop_sl, layers, hbm_bytes, 1e6 * hbm_bytes * B / HBM_PEAK)) if args.config == "C2" else
+                                    ("1x1 convolution + ActNorm of a GlowBlock as one channel map: read + write of the level's "
+                                     "activations, %d B per sample on average over the three levels; the step itself is "
+                                     "dominated by the conditioners' library convolutions" % bytes_sl) if args.config == "C4" else
                                     ("operator-boundary bytes %d per sample-layer (x + the [d_t, 3K-1] logits + y + log_q, "
                                      "SURVEY 8d) per launch of the last-layer + spline kernel; the logits never reach "
                                      "HBM in this path, so this is the yardstick, not the traffic" % bytes_sl)}}
@@ -263,9 +295,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1 << 20, help="samples per GPU (weak scaling) or in total (strong)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: every rank holds --batch samples; strong: --batch samples in total, split over the ranks")
-    ap.add_argument("--config", choices=["C3", "C2", "C5"], default="C3",
+    ap.add_argument("--config", choices=["C3", "C2", "C4", "C5"], default="C3",
                     help="C3 (default) is the headline metric's configuration; C2 (D=32, 8 affine couplings, batch 262144) "
-                         "and C5 (D=1024, 24 RQS couplings, 16 bins, the per-GPU shard 524288) are BASELINE.json's other "
+                         "C4 (3x32x32 multiscale Glow, 16384 images per GPU) and C5 (D=1024, 24 RQS couplings, 16 bins, the per-GPU shard 524288) are BASELINE.json's other "
                          "GPU configurations, reported with their own roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split", action="store_true",

@@ -437,6 +437,28 @@ def test_affine_stack_single_launch_matches_per_layer(hip, d, widths, mode, spli
         assert torch.equal(z1, z0), (d, b)
         assert_close(lp1, lp0.cpu(), rtol=2e-6, atol=2e-5, what="stack log_prob d=%d b=%d" % (d, b))
         assert_close(lq1, lq0.cpu(), rtol=2e-6, atol=2e-5, what="stack sample log_q d=%d b=%d" % (d, b))
+    # the run's concatenated weight buffer follows the parameters: an in-place update (bumps _version) is seen at the
+    # next call in BOTH directions, at the same address (captured HIP graphs keep reading it); a .data edit after
+    # refresh_packed
+    with torch.no_grad():
+        model.fuse_affine_stacks = True
+        model.log_prob(x)
+        addr = model.flows[0].__dict__['_fused_affine_stack']['wpack'].data_ptr()
+        for step in range(2):
+            for p in model.parameters():
+                if step == 0:
+                    p.add_(0.01 * torch.randn_like(p))
+                else:
+                    p.data.add_(0.01 * torch.randn_like(p))
+            if step == 1:
+                nf.refresh_packed(model)
+            model.fuse_affine_stacks = True
+            lp1 = model.log_prob(x)
+            z1, _ = model.sample_from(eps)
+            assert model.flows[0].__dict__['_fused_affine_stack']['wpack'].data_ptr() == addr
+            model.fuse_affine_stacks = False
+            assert_close(lp1, model.log_prob(x).cpu(), rtol=2e-6, atol=2e-5, what="stack after weight update %d" % step)
+            assert torch.equal(z1, model.sample_from(eps)[0])
     # a run interrupted by another flow: two launches around it, same results
     model.flows.insert(8, nf.flows.AffineConstFlow((d,)).cuda())
     with torch.no_grad():
@@ -855,6 +877,9 @@ def test_channel_mix_kernel(hip, c, h, w):
         scale = float(ref64.abs().max())
         e_got, e_ref = float((got.double() - ref64).abs().max()), float((ref32.double() - ref64).abs().max())
         assert got.shape == x.shape and e_got <= 2.0 * e_ref + 1e-6 * scale, (c, b, e_got, e_ref)
+        if h * w == 1:       # rows of a [B, C] matrix (the LU linear layer): the 16-byte store variant
+            got2 = _lib.channel_mix(x.view(b, c), mat, vec)
+            assert torch.equal(got2, got.view(b, c))
     with pytest.raises(_lib.VcnfError):
         _lib.channel_mix(torch.randn(2, 6, 2, 2, device="cuda"), torch.eye(6, device="cuda"), torch.zeros(6, device="cuda"))
 
@@ -1034,6 +1059,12 @@ def test_g14_lu_linear_permute(hip, d):
             z, ld = fn(x)
             parity(z, fx["%s/%s_z32" % (tag, dirn)], fx["%s/%s_z64" % (tag, dirn)], rtol=1e-5, atol=1e-5, what=dirn + " z")
             assert_close(ld, fx["%s/%s_ld32" % (tag, dirn)], what=dirn + " ld", rtol=1e-6, atol=1e-6)
+        # widths the channel-mix kernel covers (multiples of 4 up to 64) take it: one launch per direction
+        events = []
+        _lib.EVENT_SINK = events
+        lay.forward(x)
+        _lib.EVENT_SINK = None
+        assert len([e for e in events if e[2] == "channel_mix"]) == (1 if d % 4 == 0 else 0)
         # the stand-alone permutation module is the HIP column gather
         p, _ = lay.permutation(x)
         assert torch.equal(p.cpu(), x.cpu()[:, lay.permutation._permutation.cpu()])

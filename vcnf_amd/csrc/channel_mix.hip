@@ -32,8 +32,10 @@ struct MixArgs {
 
 constexpr int kMixBlock = 256;
 
-// CB = row blocks of 16 output channels, KS = k-steps of 4 input channels (C = 4 KS <= 16 CB)
-template <int CB, int KS>
+// CB = row blocks of 16 output channels, KS = k-steps of 4 input channels (C = 4 KS <= 16 CB).  ROWS: inner = 1, the
+// "pixels" are the rows of a [B, C] matrix (the LU-parameterised linear layer between spline couplings,
+// flows/mixing.py:352-470): a lane's four output channels are adjacent in memory and leave as one 16-byte store.
+template <int CB, int KS, bool ROWS>
 __global__ __launch_bounds__(kMixBlock) void channel_mix_kernel(const MixArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -50,39 +52,62 @@ __global__ __launch_bounds__(kMixBlock) void channel_mix_kernel(const MixArgs a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias[ob][r] = (16 * ob + 4 * q + r) < C ? a.v[16 * ob + 4 * q + r] : 0.f;
   }
-  const long long ntiles = (a.npix + 15) / 16;
+  // two 16-pixel tiles per pass: both tiles' loads are in flight together and neighbouring 64-byte segments of a
+  // channel row are requested by the same wave
+  constexpr int NT = 2;
+  const long long ntiles = (a.npix + 16 * NT - 1) / (16 * NT);
   const long long stride = (long long)gridDim.x * (kMixBlock / 64);
   const long long plane = (long long)C * a.inner;
   for (long long t = (long long)blockIdx.x * (kMixBlock / 64) + wave; t < ntiles; t += stride) {
-    const long long g = t * 16 + m16;                 // pixel index over (b, p)
-    const bool ok = g < a.npix;
-    const long long b = ok ? g / a.inner : 0;
-    const long long base = b * plane + (ok ? g - b * a.inner : 0);
-    float xv[KS];
+    bool ok[NT];
+    long long base[NT];
+    float xv[NT][KS];
 #pragma unroll
-    for (int j = 0; j < KS; ++j) xv[j] = ok ? a.x[base + (4 * j + q) * a.inner] : 0.f;
-    floatx4 acc[CB];
+    for (int c = 0; c < NT; ++c) {
+      const long long g = (t * NT + c) * 16 + m16;            // pixel index over (b, p)
+      ok[c] = g < a.npix;
+      const long long b = ROWS ? (ok[c] ? g : 0) : (ok[c] ? g / a.inner : 0);
+      base[c] = ROWS ? b * C : b * plane + (ok[c] ? g - b * a.inner : 0);
 #pragma unroll
-    for (int ob = 0; ob < CB; ++ob) acc[ob] = bias[ob];
+      for (int j = 0; j < KS; ++j) xv[c][j] = ok[c] ? a.x[base[c] + (ROWS ? 4 * j + q : (4 * j + q) * a.inner)] : 0.f;
+    }
+    floatx4 acc[NT][CB];
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+      for (int ob = 0; ob < CB; ++ob) acc[c][ob] = bias[ob];
 #pragma unroll
     for (int j = 0; j < KS; ++j)
 #pragma unroll
-      for (int ob = 0; ob < CB; ++ob) acc[ob] = mfma4(wa[ob][j], xv[j], acc[ob]);
-    if (ok) {
-#pragma unroll
       for (int ob = 0; ob < CB; ++ob)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * ob + 4 * q + r;
-          if (row < C) a.y[base + row * a.inner] = acc[ob][r];
+        for (int c = 0; c < NT; ++c) acc[c][ob] = mfma4(wa[ob][j], xv[c][j], acc[c][ob]);
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      if (ok[c]) {
+#pragma unroll
+        for (int ob = 0; ob < CB; ++ob) {
+          if (ROWS) {
+            if (16 * ob + 4 * q < C) *reinterpret_cast<floatx4*>(a.y + base[c] + 16 * ob + 4 * q) = acc[c][ob];   // C % 4 == 0
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * ob + 4 * q + r;
+              if (row < C) a.y[base[c] + row * a.inner] = acc[c][ob][r];
+            }
+          }
         }
+      }
     }
   }
 }
 
 template <int CB, int KS>
 static void launch_mix(const MixArgs& a, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((channel_mix_kernel<CB, KS>), grid, dim3(kMixBlock), 0, st, a);
+  if (a.inner == 1 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0)
+    hipLaunchKernelGGL((channel_mix_kernel<CB, KS, true>), grid, dim3(kMixBlock), 0, st, a);
+  else
+    hipLaunchKernelGGL((channel_mix_kernel<CB, KS, false>), grid, dim3(kMixBlock), 0, st, a);
 }
 
 }  // namespace vcnf
@@ -101,7 +126,7 @@ extern "C" int vcnf_channel_mix_f32(const float* x, float* y, const float* matri
   if (!x || !y || !matrix || !shift) return VCNF_ERR_NULL;
   MixArgs a;
   a.x = x; a.y = y; a.M = matrix; a.v = shift; a.npix = batch * inner; a.inner = inner; a.C = channels;
-  const long long blocks = (a.npix + 63) / 64;
+  const long long blocks = (a.npix + 127) / 128;
   const long long cap = 256 * 16;
   dim3 grid((unsigned)(blocks < cap ? blocks : cap));
   hipStream_t st = (hipStream_t)stream;

@@ -5,7 +5,8 @@ Inference runs the 1x1 convolution and the ActNorm as ONE per-pixel channel map 
     sampling direction (glow.py:59-65):  z -> exp(s) * (W^-1 z) + t            M = diag(exp s) W^-1,  v = t
     density direction  (glow.py:67-73):  z -> W ((z - t) * exp(-s))            M = W diag(exp -s),    v = -W (t exp -s)
 with M, v composed in fp64 from the layer parameters (W = P L U or the dense W, mixing.py:71-95) and cached per
-direction, keyed on the parameters' (data_ptr, _version) like the packed conditioner weights (fused.refresh_packed)."""
+direction, keyed on the parameters' (data_ptr, _version) like the packed conditioner weights and rewritten in place
+(fused.refresh_packed invalidates it)."""
 import torch
 from torch import nn
 
@@ -45,7 +46,7 @@ class GlowBlock(Flow):
         conv, norm = self._mixer_parts()
         if not self.fused_mixers or conv is None or z.dim() != 4 or not z.is_cuda or z.dtype != torch.float32:
             return False
-        cache = self.__dict__.setdefault('_mats', {})
+        cache = self.__dict__.setdefault('_mix_cache', {})
         if not cache.get('norm_ready'):           # the first batch initialises the ActNorm on the plain path
             if not bool(norm.data_dep_init_done > 0.):
                 return False
@@ -61,10 +62,10 @@ class GlowBlock(Flow):
         conv, norm = self._mixer_parts()
         params = list(conv.parameters()) + [norm.s, norm.t]
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
-        cache = self.__dict__.setdefault('_mats', {})
+        cache = self.__dict__.setdefault('_mix_cache', {})
         hit = cache.get(sampling)
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        if hit is not None and hit['key'] == key:
+            return hit['out']
         with torch.no_grad():
             c = conv.num_channels
             if conv.use_lu:
@@ -89,7 +90,11 @@ class GlowBlock(Flow):
                 vec = -(w @ (t * torch.exp(-s)))
                 ld = ld_w - torch.sum(norm.s)
             out = (mat.float().contiguous(), vec.float().contiguous(), ld.float())
-        cache[sampling] = (key, out)
+            if hit is not None and hit['out'][0].device == out[0].device:
+                for old, new in zip(hit['out'], out):      # in place: a captured HIP graph keeps reading these addresses
+                    old.copy_(new)
+                out = hit['out']
+        cache[sampling] = {'key': key, 'out': out}
         return out
 
     def _mix(self, z, sampling):

@@ -1,13 +1,15 @@
-"""Channel mixing layers.  Permutations are a HIP column gather; the invertible 1x1
-convolution is a dense C x C contraction with a parameter-only log-det and runs on
-PyTorch-ROCm (not a hand-kernel target).
-Reference: normflow/flows/mixing.py:10-54 (Permute), :57-128 (Invertible1x1Conv)."""
+"""Channel mixing layers.  Permutations are a HIP column gather.  The invertible 1x1 convolution and the
+LU-parameterised linear layer are dense C x C maps with a parameter-only log-det: at inference they run on
+csrc/channel_mix.hip (exact fp32 matrix instructions, one pass over the activations; inside a GlowBlock the 1x1
+convolution is composed with the ActNorm next to it, flows/affine/glow.py) for C a multiple of 4 up to 64; other
+widths and the differentiable path use PyTorch-ROCm library calls.
+Reference: normflow/flows/mixing.py:10-54 (Permute), :57-128 (Invertible1x1Conv), :352-492 (_LULinear)."""
 import torch
 from torch import nn
 from torch.nn import functional as F
 
 from .base import Flow
-from .. import _lib
+from .. import _lib, autograd
 
 
 class Permute(Flow):
@@ -232,7 +234,32 @@ class _LULinear(Flow):
             self._mats[key] = m.detach()
         return m
 
+    def _mix_operands(self, inverse, col_index):
+        """(M, v) of csrc/channel_mix.hip for this direction: out = x M^T + v, cached like ``_matrix``."""
+        params = (self.lower_entries, self.upper_entries, self.unconstrained_upper_diag, self.bias)
+        key = ('mix', bool(inverse), None if col_index is None else (col_index.data_ptr(), col_index._version),
+               str(params[0].device)) + tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._mats.get(key)
+        if hit is None:
+            with torch.no_grad():
+                m = self._matrix(inverse, col_index)                   # out = (x - bias) m   or   x m + bias
+                vec = -(self.bias.double() @ m.double()).float() if inverse else self.bias.detach().clone()
+                hit = (m.t().contiguous(), vec.contiguous())
+            if len(self._mats) > 8:
+                self._mats.clear()
+            self._mats[key] = hit
+        return hit
+
     def _apply_linear(self, inputs, inverse, col_index=None):
+        params = (self.lower_entries, self.upper_entries, self.unconstrained_upper_diag, self.bias)
+        if (self.fused_mix and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
+                and not autograd.needs_grad(inputs, *params)
+                and _lib.lib().vcnf_channel_mix_supported(self.features)):
+            # one launch on the exact-fp32 matrix instructions instead of a library GEMM + elementwise kernels
+            mat, vec = self._mix_operands(inverse, col_index)
+            out = _lib.channel_mix(inputs, mat, vec)
+            ld = -self.logabsdet() if inverse else self.logabsdet()
+            return out, ld * inputs.new_ones(out.shape[0])
         m = self._matrix(inverse, col_index)
         if inverse:
             out = (inputs - self.bias) @ m
@@ -241,6 +268,8 @@ class _LULinear(Flow):
             out = torch.addmm(self.bias, inputs, m)
             ld = self.logabsdet()
         return out, ld * inputs.new_ones(out.shape[0])
+
+    fused_mix = True
 
     def forward(self, inputs, context=None):
         return self._apply_linear(inputs, False)

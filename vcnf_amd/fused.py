@@ -248,7 +248,7 @@ def run(coupling, inputs, context, sampling, log_q=None, sign=1.0):
 def refresh_packed(module):
     """Invalidate every packed / derived weight cache under ``module``: the fused kernels read re-ordered copies of
     the conditioner weights (this file, fused_affine.py, fused_final.py) and ``_LULinear`` a cached L.U product,
-    all keyed on (data_ptr, _version) of the parameters.  An in-place update through ``.data`` (``p.data.copy_(ema)``,
+    all keyed on (data_ptr, _version) of the parameters (likewise a GlowBlock's composed 1x1 convolution + ActNorm map).  An in-place update through ``.data`` (``p.data.copy_(ema)``,
     initialisation on ``.data`` - an idiom of the reference API) does NOT bump ``_version``: call this afterwards.
     ``NormalizingFlow`` / ``MultiscaleFlow`` call it on train() / eval() transitions and after load_state_dict().
     Buffers are rewritten in place at the next use, so a captured HIP graph keeps its addresses."""
@@ -256,9 +256,14 @@ def refresh_packed(module):
         d = m.__dict__
         if d.get('_fused_pack') is not None:
             d['_fused_pack'] = (None, d['_fused_pack'][1])
-        for name in ('_fused_affine_pack', '_fused_final_pack', '_fused_trunk_pack'):
+        for name in ('_fused_affine_pack', '_fused_affine_stack', '_fused_final_pack', '_fused_trunk_pack'):
             if isinstance(d.get(name), dict):
                 d[name]['key'] = None
         if isinstance(d.get('_mats'), dict):
             d['_mats'].clear()
+        if isinstance(d.get('_mix_cache'), dict):           # GlowBlock: composed 1x1 convolution + ActNorm per direction
+            for k, v in d['_mix_cache'].items():
+                if isinstance(v, dict):
+                    v['key'] = None
+            d['_mix_cache']['norm_ready'] = False
     return module

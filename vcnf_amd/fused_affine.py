@@ -165,11 +165,18 @@ def run_stack(steps, trailing, z, code, inverse, log_q, sign):
     (l1, _, l3), slope = _linears(first.flows[1].param_map)
     bufs = [packed_weights(b)[0] for b, _ in steps]
     cache = first.__dict__.setdefault('_fused_affine_stack', {})
-    key = (bool(inverse), tuple(id(b) for b, _ in steps), tuple(t.data_ptr() for t in bufs),
+    # one weight buffer for the run, shared by both directions and rewritten IN PLACE when a layer's pack changes: a
+    # captured HIP graph keeps reading the same address (GraphedFlow.refresh)
+    key = (tuple(id(b) for b, _ in steps), tuple(t.data_ptr() for t in bufs),
            tuple(b.__dict__['_fused_affine_pack']['key'] for b, _ in steps))
     if cache.get('key') != key:
+        new = torch.cat(bufs).contiguous()
+        old = cache.get('wpack')
+        if old is not None and old.shape == new.shape and old.device == new.device:
+            old.copy_(new)
+        else:
+            cache['wpack'] = new
         cache['key'] = key
-        cache['wpack'] = torch.cat(bufs).contiguous()
     rows, layers = [], []
     for blk, perm in steps:
         gb = -1
@@ -182,6 +189,13 @@ def run_stack(steps, trailing, z, code, inverse, log_q, sign):
     if trailing is not None:
         ga = len(rows)
         rows.append(trailing._idx32(inverse, z.device))
-    gathers = torch.stack(rows).contiguous() if rows else None
+    gathers = None
+    if rows:
+        gkey = (bool(inverse), z.shape[1]) + tuple((r.data_ptr(), r._version) for r in rows)
+        hit = cache.setdefault('gathers', {}).get(bool(inverse))
+        if hit is None or hit[0] != gkey:
+            hit = (gkey, torch.stack(rows).contiguous())
+            cache['gathers'][bool(inverse)] = hit
+        gathers = hit[1]
     return _lib.affine_stack_fused(z, cache['wpack'], layers, ga, gathers, l1.in_features, l1.out_features, slope, code,
                                    inverse, logdet=log_q, sign=sign)
