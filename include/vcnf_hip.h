@@ -304,6 +304,14 @@ int vcnf_affine_stack_fused_f32(const float* x, float* y, float* logdet, int64_t
                                 const int32_t* gathers, int32_t n_gather_rows,
                                 int inverse, int ld_mode, float ld_sign, void* stream);
 
+/* Elementwise map of the masked affine autoregressive flow (flows/affine/autoregressive.py:75-103): params
+ * [batch, features, 2] = (unconstrained scale u, shift) per feature from one MADE pass (:96-103),
+ * scale = sigmoid(u + 2) + 1e-3.  inverse = 0: y = scale x + shift, logdet = sum log scale (:75-81, the flow's
+ * one-pass direction); inverse != 0: y = (x - shift) / scale, logdet = -sum log scale (:83-89, applied D times by the
+ * sequential loop :29-36).  params must be 8-byte aligned. */
+int vcnf_maf_affine_f32(const float* x, const float* params, float* out, float* logdet, int64_t batch,
+                        int32_t features, int inverse, int ld_mode, float ld_sign, void* stream);
+
 /* MaskedAffineFlow.forward / .inverse (flows/affine/coupling.py:202-211 /
  * :213-222) on z[B,D]; s,t [B,D] are the scale / shift net outputs (NULL =
  * zeros, coupling.py:192-200); b[D] the 0/1 float mask.  Non-finite s/t become

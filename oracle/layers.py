@@ -278,6 +278,31 @@ class AutoregressiveRQS:
         return y, ld.view(-1)
 
 
+class MaskedAffineAutoregressive:
+    """affine/autoregressive.py:48-103 on top of :24-36: ``forward`` is one conditioner pass with
+    scale = sigmoid(u + 2) + 1e-3, y = scale x + shift, log|det| = sum log scale (:75-81); ``inverse`` D passes from
+    zeros with y = (x - shift) / scale, log|det| = -sum log scale (:83-89).  ``conditioner(x)`` returns [B, D * 2] laid
+    out (u, shift) per feature (:96-103)."""
+
+    def __init__(self, conditioner, features):
+        self.conditioner, self.d = conditioner, features
+
+    def _scale_shift(self, params):
+        p = params.view(-1, self.d, 2)                                              # :96-103
+        return torch.sigmoid(p[..., 0] + 2.) + 1e-3, p[..., 1]                      # :77, :85
+
+    def forward(self, x):
+        scale, shift = self._scale_shift(self.conditioner(x))
+        return scale * x + shift, _row_sum(torch.log(scale))                        # :78-81
+
+    def inverse(self, x):
+        out, lad = torch.zeros_like(x), None
+        for _ in range(int(np.prod(x.shape[1:]))):                                  # :30-35
+            scale, shift = self._scale_shift(self.conditioner(out))
+            out, lad = (x - shift) / scale, -_row_sum(torch.log(scale))             # :86-89
+        return out, lad
+
+
 class LULinearPermute:
     """mixing.py:352-492: fixed permutation + linear map y = x (L U)^T + bias, L unit lower,
     diag(U) = softplus(.) + eps.  ``forward`` (sampling direction) = inverse linear map by two

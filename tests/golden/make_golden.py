@@ -751,6 +751,31 @@ def g19_autoregressive():
     save("g19_autoregressive", **out)
 
 
+def g22_maf():
+    """Masked affine autoregressive flow (flows/affine/autoregressive.py:48-103): MADE conditioner with output
+    multiplier 2, one-pass ``forward`` and the D-pass ``inverse``; plain and with context (GLU context layers)."""
+    out = {}
+    d = 7
+    r = rng(2200)
+    x = torch.from_numpy(r.standard_normal((160, d)).astype(np.float32)) * 1.5
+    ctx = torch.from_numpy(r.standard_normal((160, 3)).astype(np.float32))
+    out["x"], out["ctx"] = npy(x), npy(ctx)
+    torch.manual_seed(2200)
+
+    def case(tag, build, args):
+        call = lambda m, *a: m.forward(*a) + m.inverse(*a)
+        probe = build()
+        keep = tuple(key for key in probe.state_dict() if key.endswith("mask"))   # masks are structure, stored below
+        ents, ints, o32, o64, m = run_module_case(build, 2201, args, call, skip=keep, final_gain=1.0)
+        pack(out, tag, ents, ints, ["fwd_z", "fwd_ld", "inv_z", "inv_ld"], o32, o64)
+        for key, v in m.state_dict().items():
+            if key.endswith("mask"):
+                out[tag + "/mask/" + key] = npy(v)
+    case("plain", lambda: nf.flows.MaskedAffineAutoregressive(d, 24, num_blocks=2), [x])
+    case("ctx", lambda: nf.flows.MaskedAffineAutoregressive(d, 24, context_features=3, num_blocks=1), [x, ctx])
+    save("g22_maf", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                            # only the named cases: make_golden.py g20_c4_real_shape ...
         for name_ in sys.argv[1:]:
@@ -777,3 +802,4 @@ if __name__ == "__main__":
     g19_autoregressive()
     g20_c4_real_shape()
     g21_c5_real_depth()
+    g22_maf()

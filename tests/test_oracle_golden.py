@@ -387,3 +387,26 @@ def test_g19_autoregressive_rqs(tag):
             z, ld = fn(x)
             assert_close(z, fx["%s/%s_z%s" % (tag, dirn, suf)], what=dirn + " z", **tol)
             assert_close(ld, fx["%s/%s_ld%s" % (tag, dirn, suf)], what=dirn + " ld", **tol)
+
+def _maf_state(fx, tag, dt):
+    sd, _ = state_for(fx, tag, 2201, dt, final_gain=1.0)
+    for key, v in fx.items():
+        if key.startswith(tag + "/mask/"):
+            sd[key[len(tag) + 6:]] = T(v, dt)
+    return sd
+
+
+@pytest.mark.parametrize("tag", ["plain", "ctx"])
+def test_g22_masked_affine_autoregressive(tag):
+    """Oracle restatement of the MAF layer against the reference's outputs (fixture G22), fp32 and fp64, both
+    directions; the context case runs the MADE's GLU context layers."""
+    fx = fixture("g22_maf")
+    for dt, suf, tol in ((torch.float32, "32", dict(rtol=2e-5, atol=2e-5)), (torch.float64, "64", F64)):
+        sd = _maf_state(fx, tag, dt)
+        ctx = T(fx["ctx"], dt) if tag == "ctx" else None
+        lay = OL.MaskedAffineAutoregressive(lambda x: ON.made(sd, "autoregressive_net.", x, context=ctx), 7)
+        x = T(fx["x"], dt)
+        for dirn, fn in (("fwd", lay.forward), ("inv", lay.inverse)):
+            z, ld = fn(x)
+            assert_close(z, fx["%s/%s_z%s" % (tag, dirn, suf)], what=dirn + " z", **tol)
+            assert_close(ld, fx["%s/%s_ld%s" % (tag, dirn, suf)], what=dirn + " ld", **tol)

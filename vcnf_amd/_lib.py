@@ -75,6 +75,7 @@ PROTOTYPES = {
     "vcnf_resnet_trunk_f32": ([_P, _P, _I64, _I32, _I32, _I32, _P, _I64, _P], _INT),
     "vcnf_affine_stack_fused_f32": ([_P, _P, _P, _I64, _I32, _I32, _P, _I32, _I32, _I32, _F32, _INT, _P, _I64, _P, _I32,
                                      _INT, _INT, _F32, _P], _INT),
+    "vcnf_maf_affine_f32": ([_P, _P, _P, _P, _I64, _I32, _INT, _INT, _F32, _P], _INT),
     "vcnf_masked_affine_f32": ([_P, _P, _P, _P, _P, _P, _I64, _I32, _INT, _INT, _F32, _P], _INT),
     "vcnf_affine_const_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _INT, _P], _INT),
     "vcnf_permute_f32": ([_P, _P, _P, _I64, _I32, _I32, _P], _INT),
@@ -641,6 +642,23 @@ def masked_affine(z, s, t, bmask, inverse, logdet=None, sign=1.0):
                                           b, d, int(bool(inverse)), mode, float(sign), _stream())
     _check(st, "vcnf_masked_affine_f32")
     return out, logdet
+
+
+def maf_affine(x, params, inverse):
+    """Masked-affine-autoregressive elementwise map on a MADE output [B, D * 2] (csrc/affine_kernels.hip::
+    maf_affine_kernel): returns (y, log_det[B])."""
+    dev = require_device(x, params)
+    x, params = x.contiguous(), params.contiguous()
+    b, d = x.shape
+    if params.shape[0] != b or params[0].numel() != 2 * d:
+        raise VcnfError("maf_affine: params %s do not match inputs %s" % (tuple(params.shape), tuple(x.shape)))
+    out = torch.empty_like(x)
+    ld = torch.empty(b, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = lib().vcnf_maf_affine_f32(_ptr(x), _ptr(params), _ptr(out), _ptr(ld), b, d, int(bool(inverse)), LD_STORE, 1.0,
+                                       _stream())
+    _check(st, "vcnf_maf_affine_f32")
+    return out, ld
 
 
 def affine_const(z, s, t, inverse):

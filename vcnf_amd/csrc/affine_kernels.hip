@@ -98,6 +98,39 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(const AffineArg
   }
 }
 
+// ------------------------------------------------------------------ autoregressive affine (MAF)
+// flows/affine/autoregressive.py:75-103: params [B, D, 2] = (unconstrained scale, shift) per feature from a MADE pass,
+// scale = sigmoid(u + 2) + 1e-3; density direction y = scale x + shift, log|det| = sum log scale; the other direction
+// y = (x - shift) / scale, log|det| = -sum log scale (called D times by the sampling loop, :29-36).
+struct MafArgs {
+  const float* x;
+  const float* param;
+  float* out;
+  float* logdet;
+  long long B;
+  int D, inverse, G, ld_mode;
+  float ld_sign;
+};
+
+__global__ __launch_bounds__(kBlock) void maf_affine_kernel(const MafArgs a) {
+  const int g = threadIdx.x & (a.G - 1);
+  const int per_block = kBlock / a.G;
+  for (long long b = (long long)blockIdx.x * per_block + threadIdx.x / a.G; b < a.B;
+       b += (long long)gridDim.x * per_block) {
+    const float2* pr = reinterpret_cast<const float2*>(a.param) + b * a.D;
+    float acc = 0.f;
+    for (int j = g; j < a.D; j += a.G) {
+      const float2 p = pr[j];
+      const float scale = sigmoid_f(p.x + 2.f) + 1e-3f;
+      const float v = a.x[b * a.D + j];
+      a.out[b * a.D + j] = a.inverse ? (v - p.y) / scale : scale * v + p.y;
+      acc += logf(scale);
+    }
+    acc = group_sum(acc, a.G);
+    if (g == 0) put_ld(a.logdet, b, a.ld_sign * (a.inverse ? -acc : acc), a.ld_mode);
+  }
+}
+
 // ------------------------------------------------------------------ masked affine
 struct MaskedArgs {
   const float *z, *s, *t, *b;
@@ -239,6 +272,18 @@ extern "C" int vcnf_affine_coupling_f32(const float* z, const float* param, floa
   AffineArgs a{z, param, out, logdet, batch, channels, inner, t_off, d_t, scale_map, inverse ? 1 : 0,
                pick_lanes((long long)channels * inner), ld_mode, ld_sign};
   hipLaunchKernelGGL(affine_coupling_kernel, grid_for(batch, a.G), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return launched();
+}
+
+extern "C" int vcnf_maf_affine_f32(const float* x, const float* params, float* out, float* logdet, int64_t batch,
+                                   int32_t features, int inverse, int ld_mode, float ld_sign, void* stream) {
+  if (batch < 0 || features < 1) return VCNF_ERR_SHAPE;
+  if (!ok_ld(ld_mode)) return VCNF_ERR_UNSUPPORTED;
+  if (batch == 0) return VCNF_OK;
+  if (!x || !params || !out || !logdet) return VCNF_ERR_NULL;
+  if (reinterpret_cast<uintptr_t>(params) & 7) return VCNF_ERR_ALIGN;
+  MafArgs a{x, params, out, logdet, batch, features, inverse ? 1 : 0, pick_lanes(features), ld_mode, ld_sign};
+  hipLaunchKernelGGL(maf_affine_kernel, grid_for(batch, a.G), dim3(kBlock), 0, (hipStream_t)stream, a);
   return launched();
 }
 

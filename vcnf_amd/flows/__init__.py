@@ -5,6 +5,7 @@ from .normalization import ActNorm                                              
 from .affine import (AffineConstFlow, AffineCoupling, MaskedAffineFlow,           # noqa: F401
                      AffineCouplingBlock)
 from .affine.glow import GlowBlock                                                # noqa: F401
+from .affine.autoregressive import MaskedAffineAutoregressive                     # noqa: F401
 from .neural_spline import (CoupledRationalQuadraticSpline,                       # noqa: F401
                             CircularCoupledRationalQuadraticSpline, AutoregressiveRationalQuadraticSpline,
                             CircularAutoregressiveRationalQuadraticSpline,
