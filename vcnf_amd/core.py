@@ -68,7 +68,7 @@ class NormalizingFlow(_PackedWeightsMixin, nn.Module):
             ctx = {'context': context} if (context is not None and getattr(flow, 'takes_context', False)) else {}
             # a run of one-kernel affine layers (and the Permutes between them) is ONE launch
             if i >= resume and isinstance(flow, (Permute, AffineCouplingBlock)) and self.fuse_affine_stacks:
-                plan = fused_affine.plan_stack(order, i, z, True)
+                plan = fused_affine.cached_plan(self, order, i, z, True)
                 if plan is not None:
                     resume, steps, trailing = plan
                     core_ = steps[0][0].flows[1]
@@ -115,7 +115,7 @@ class NormalizingFlow(_PackedWeightsMixin, nn.Module):
                 continue
             ctx = {'context': context} if (context is not None and getattr(flow, 'takes_context', False)) else {}
             if i >= resume and isinstance(flow, (Permute, AffineCouplingBlock)) and self.fuse_affine_stacks:
-                plan = fused_affine.plan_stack(order, i, z, False)
+                plan = fused_affine.cached_plan(self, order, i, z, False)
                 if plan is not None:
                     resume, steps, trailing = plan
                     core_ = steps[0][0].flows[1]

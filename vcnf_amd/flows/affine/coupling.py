@@ -144,9 +144,11 @@ class AffineCouplingBlock(Flow):
 
     def fusable(self, z):
         """True when this call would take the one-kernel path (which can also absorb a Permute)."""
-        core = self.flows[1]
-        return (self.fused and not autograd.needs_grad(z, *core.param_map.parameters())
-                and fused_affine.eligible(self, z))
+        if not self.fused:
+            return False
+        if torch.is_grad_enabled() and autograd.needs_grad(z, *self.flows[1].param_map.parameters()):
+            return False
+        return fused_affine.eligible(self, z)
 
     def run_with_permute(self, z, inverse, log_q, sign, in_gather=None, out_gather=None):
         """One-kernel layer with a neighbouring Permute folded into its load / store indexing."""
@@ -167,7 +169,7 @@ class AffineCouplingBlock(Flow):
             return out, (ld if sign == 1.0 else sign * ld)
         core = self.flows[1]
         code = _scale_code(core.scale, core.scale_map)
-        if (self.fused and not autograd.needs_grad(z, log_q, *core.param_map.parameters())
+        if (self.fused and not (torch.is_grad_enabled() and autograd.needs_grad(z, log_q, *core.param_map.parameters()))
                 and fused_affine.eligible(self, z)):
             # conditioner + affine map + log|det| in one kernel (csrc/fused_affine.hip)
             return fused_affine.run(self, z, code, inverse, log_q, sign)

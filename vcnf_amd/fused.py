@@ -259,6 +259,9 @@ def refresh_packed(module):
         for name in ('_fused_affine_pack', '_fused_affine_stack', '_fused_final_pack', '_fused_trunk_pack'):
             if isinstance(d.get(name), dict):
                 d[name]['key'] = None
+                d[name].pop('desc', None)                   # stack launch descriptors (permutation rows)
+        if isinstance(d.get('_stack_plans'), dict):         # NormalizingFlow: memoised stack plans
+            d['_stack_plans'].clear()
         if isinstance(d.get('_mats'), dict):
             d['_mats'].clear()
         if isinstance(d.get('_mix_cache'), dict):           # GlowBlock: composed 1x1 convolution + ActNorm per direction

@@ -14,7 +14,19 @@ from . import _lib
 
 
 def _linears(mlp):
-    """(linears, slope) when ``mlp`` is Linear, LeakyReLU, Linear, LeakyReLU, Linear; else None."""
+    """(linears, slope) when ``mlp`` is Linear, LeakyReLU, Linear, LeakyReLU, Linear; else None.  Cached on the module
+    (keyed on the identity of its layers): this runs for every layer of every evaluation."""
+    net = getattr(mlp, 'net', None)
+    key = tuple(map(id, net)) if isinstance(net, nn.Sequential) else None
+    hit = mlp.__dict__.get('_fa_linears')
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    got = _linears_uncached(mlp)
+    mlp.__dict__['_fa_linears'] = (key, got)
+    return got
+
+
+def _linears_uncached(mlp):
     from .nets.mlp import MLP
     if type(mlp) is not MLP:
         return None
@@ -159,43 +171,62 @@ def plan_stack(order, start, z, inverse):
     return j, steps, pending
 
 
+def cached_plan(owner, order, start, z, inverse):
+    """plan_stack memoised on the calling model for evaluations without autograd: the plan depends only on the
+    modules in ``order`` (identity, their ``fused`` switches), the position, the direction and the feature count."""
+    if torch.is_grad_enabled():
+        return plan_stack(order, start, z, inverse)
+    key = (start, bool(inverse), z.dim(), z.shape[-1], z.dtype, tuple(map(id, order)),
+           tuple(getattr(f, 'fused', None) for f in order))
+    plans = owner.__dict__.setdefault('_stack_plans', {})
+    if key not in plans:
+        if len(plans) > 32:
+            plans.clear()
+        plans[key] = plan_stack(order, start, z, inverse)
+    return plans[key]
+
+
 def run_stack(steps, trailing, z, code, inverse, log_q, sign):
     """Execute a planned run (see plan_stack) in one launch."""
     first = steps[0][0]
-    (l1, _, l3), slope = _linears(first.flows[1].param_map)
-    bufs = [packed_weights(b)[0] for b, _ in steps]
     cache = first.__dict__.setdefault('_fused_affine_stack', {})
-    # one weight buffer for the run, shared by both directions and rewritten IN PLACE when a layer's pack changes: a
-    # captured HIP graph keeps reading the same address (GraphedFlow.refresh)
-    key = (tuple(id(b) for b, _ in steps), tuple(t.data_ptr() for t in bufs),
-           tuple(b.__dict__['_fused_affine_pack']['key'] for b, _ in steps))
+    # validity of everything cached below: the run's blocks and the (address, version) of their conditioner parameters
+    ids = tuple(id(b) for b, _ in steps)
+    if cache.get('ids') != ids:
+        cache.clear()
+        cache['ids'] = ids
+        cache['params'] = [p for b, _ in steps for lin in _linears(b.flows[1].param_map)[0] for p in (lin.weight, lin.bias)]
+    key = tuple((p.data_ptr(), p._version) for p in cache['params'])
     if cache.get('key') != key:
-        new = torch.cat(bufs).contiguous()
+        # one weight buffer for the run, shared by both directions and rewritten IN PLACE when a layer's pack changes: a
+        # captured HIP graph keeps reading the same address (GraphedFlow.refresh)
+        new = torch.cat([packed_weights(b)[0] for b, _ in steps]).contiguous()
         old = cache.get('wpack')
         if old is not None and old.shape == new.shape and old.device == new.device:
             old.copy_(new)
         else:
             cache['wpack'] = new
         cache['key'] = key
-    rows, layers = [], []
-    for blk, perm in steps:
-        gb = -1
-        if perm is not None:
-            gb = len(rows)
-            rows.append(perm._idx32(inverse, z.device))
-        cond_off, t_off, d_t = _geometry(blk, z.shape[1])
-        layers.append((cond_off, t_off, d_t, gb))
-    ga = -1
-    if trailing is not None:
-        ga = len(rows)
-        rows.append(trailing._idx32(inverse, z.device))
-    gathers = None
-    if rows:
-        gkey = (bool(inverse), z.shape[1]) + tuple((r.data_ptr(), r._version) for r in rows)
-        hit = cache.setdefault('gathers', {}).get(bool(inverse))
-        if hit is None or hit[0] != gkey:
-            hit = (gkey, torch.stack(rows).contiguous())
-            cache['gathers'][bool(inverse)] = hit
-        gathers = hit[1]
-    return _lib.affine_stack_fused(z, cache['wpack'], layers, ga, gathers, l1.in_features, l1.out_features, slope, code,
+    dkey = (bool(inverse), z.shape[1], str(z.device), None if trailing is None else id(trailing),
+            tuple(None if p is None else id(p) for _, p in steps))
+    desc = cache.setdefault('desc', {}).get(bool(inverse))
+    if desc is None or desc[0] != dkey:
+        (l1, _, l3), slope = _linears(first.flows[1].param_map)
+        rows, layers = [], []
+        for blk, perm in steps:
+            gb = -1
+            if perm is not None:
+                gb = len(rows)
+                rows.append(perm._idx32(inverse, z.device))
+            cond_off, t_off, d_t = _geometry(blk, z.shape[1])
+            layers.append((cond_off, t_off, d_t, gb))
+        ga = -1
+        if trailing is not None:
+            ga = len(rows)
+            rows.append(trailing._idx32(inverse, z.device))
+        gathers = torch.stack(rows).contiguous() if rows else None
+        desc = (dkey, layers, ga, gathers, l1.in_features, l1.out_features, slope)
+        cache['desc'][bool(inverse)] = desc
+    _, layers, ga, gathers, c_in, hidden, slope = desc
+    return _lib.affine_stack_fused(z, cache['wpack'], layers, ga, gathers, c_in, hidden, slope, code,
                                    inverse, logdet=log_q, sign=sign)

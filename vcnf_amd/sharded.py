@@ -84,8 +84,10 @@ class ShardedEvaluator:
 
     def reduce_stats(self, log_q):
         """[sum, count] over all ranks as fp64, one fused all-reduce."""
-        stats = torch.stack([log_q.double().sum(), torch.tensor(float(log_q.numel()), dtype=torch.float64,
-                                                                  device=log_q.device)])
+        # (no torch.tensor(..., device=...) here: that is a synchronous host -> device copy per call)
+        stats = torch.empty(2, dtype=torch.float64, device=log_q.device)
+        stats[0] = log_q.sum(dtype=torch.float64)
+        stats[1] = float(log_q.numel())
         w, _ = self._world()
         if w > 1:
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
