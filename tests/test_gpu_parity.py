@@ -1028,6 +1028,43 @@ def test_g21_c5_real_depth(hip):
     nf.check_discriminant()
 
 
+def test_c5_full_shard_one_pass(hip):
+    """Config C5 at BASELINE.json's per-GPU size: the 524 288 x 1024 shard in ONE pass (no logits are materialised, so
+    it fits: the three launches per layer of vcnf_amd/fused_final.py at their large-batch tile shapes - two tiles per
+    wave in the trunk kernel).  Size-independent properties: the pass reproduces, bit for bit, the rows of a
+    65 536-sample and of a 4 096-sample evaluation (per-sample arithmetic does not depend on the tile shape), and
+    sample -> log_prob reproduces log_q as well as it does at 32 768 samples (test_g21_c5_real_depth)."""
+    fx = fixture("g21_c5_real_depth")
+    sd, _ = state_for(fx, "c5", 2101, final_gain=1.0)
+    flows = [nf.flows.CoupledRationalQuadraticSpline(1024, 2, 128, 16, reverse_mask=bool(i % 2)) for i in range(24)]
+    model = load(nf.NormalizingFlow(nf.distributions.DiagGaussian(1024), flows), sd)
+    b = 524288
+    gen = torch.Generator(device="cuda").manual_seed(12)
+    with torch.no_grad():
+        eps = torch.randn(b, 1024, device="cuda", generator=gen)
+        z, lq = model.sample_from(eps)
+        assert torch.isfinite(z).all() and torch.isfinite(lq).all()
+        for lo, n in ((0, 4096), (262144 - 7, 65536), (b - 4096, 4096)):
+            zs, lqs = model.sample_from(eps[lo:lo + n])
+            assert torch.equal(zs, z[lo:lo + n]) and torch.equal(lqs, lq[lo:lo + n]), (lo, n)
+        eps32 = eps[:32].cpu()
+        del eps
+        lp = model.log_prob(z)
+        assert torch.equal(model.log_prob(z[1000:1000 + 8192]), lp[1000:1000 + 8192])
+        err = (lp - lq).abs() / (1.0 + lq.abs())
+        print("C5 full shard (524288 x 1024, one pass) round trip log_q rel err: max %.3e mean %.3e" % (
+            float(err.max()), float(err.mean())))
+        # yardstick as in test_g21_c5_real_depth: the oracle's own fp32 round trip on the first 32 samples (24 layers of
+        # a random-weight model amplify rounding: the reference's round trip is ~3e-3 relative itself); the mean over the
+        # shard must stay at that level, the max may reach further into the tail with 16 384x more samples
+        sdc = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        o_lq, _ = oracle_round_trip(oracle_crqs_stack(sdc, 24, 16, 3.0, 128), eps32, None)
+        anchored(err[:32], o_lq, "C5 full shard round trip log_q, first 32")
+        assert float(err.mean()) <= 2.0 * float(o_lq.mean()) + 1e-6 and float(err.max()) <= 64.0 * float(o_lq.max())
+    nf.check_discriminant()
+    assert nf.check_saturation(model=model) == 0
+
+
 def test_actnorm_data_dependent_init(hip):
     """First batch standardises the output (normalization.py:20-27), then parameters stay."""
     torch.manual_seed(31)
