@@ -19,6 +19,7 @@
 
 #include "../../include/vcnf_hip.h"
 #include "rqs_math.hpp"
+#include "rqs_lean.hpp"
 
 namespace vcnf {
 
@@ -212,6 +213,9 @@ __global__ __launch_bounds__(kBlock) void rqs_coupling_pf_kernel(const CouplingA
 
   const int g = tid & (a.G - 1);
   const int s = tid / a.G;
+  const bool lean = c.tails == 1;
+  const LeanConst lc = make_lean_const(c);
+  const float s_wh = c.wh_scale * kLog2e;
   const int rowlen4 = (a.d_t * a.P) >> 2;     // float4 per params row (host guarantees divisibility)
   const int d4 = a.D >> 2;
   const long long ntiles = (a.B + a.S - 1) / a.S;
@@ -262,9 +266,24 @@ __global__ __launch_bounds__(kBlock) void rqs_coupling_pf_kernel(const CouplingA
       for (int j = g; j < a.d_t; j += a.G) {
         const int col = tfi[j];
         const float xv = xt[s * a.D + col];
-        PackedLogits p{pt + s * seg + j * a.P, K, c.wh_scale, c.edge_logit, c.tails};
         float yv, lad;
-        rqs_point<KT, INV>(xv, p, c, yv, lad, bad);
+        if constexpr (KT >= 4 && KT % 2 == 0) {
+          if (lean) {
+            // linear tails with a compile-time bin count: rqs_lean.hpp's evaluation (a third fewer vector instructions;
+            // this kernel's time is its HBM stream plus what the vector unit does not hide behind it)
+            float lg[3 * KT - 1];
+            const float* q = pt + s * seg + j * a.P;
+#pragma unroll
+            for (int t = 0; t < 3 * KT - 1; ++t) lg[t] = q[t] * (t < 2 * KT ? s_wh : kLog2e);
+            rqs_lean_eval<KT, INV>(xv, lg, lc, yv, lad, bad);
+          } else {
+            PackedLogits p{pt + s * seg + j * a.P, K, c.wh_scale, c.edge_logit, c.tails};
+            rqs_point<KT, INV>(xv, p, c, yv, lad, bad);
+          }
+        } else {
+          PackedLogits p{pt + s * seg + j * a.P, K, c.wh_scale, c.edge_logit, c.tails};
+          rqs_point<KT, INV>(xv, p, c, yv, lad, bad);
+        }
         yt[s * a.D + col] = yv;
         acc += lad;
       }
