@@ -216,6 +216,22 @@ int vcnf_channel_mix_supported(int32_t channels);
 int vcnf_channel_mix_f32(const float* x, float* y, const float* matrix, const float* shift,
                          int64_t batch, int32_t channels, int64_t inner, void* stream);
 
+/* 1x1 convolution of an NCHW batch with the bias adds and LeakyReLUs around it in one pass (nets/cnn.py:20-52, the
+ * middle layer of the Glow conditioner flows/affine/glow.py:37-47):
+ *   y[b, o, p] = act_out( sum_c W[o, c] * act_in(x[b, c, p] + in_bias[c]) + out_bias[o] ),  act(t) = t >= 0 ? t : slope t
+ * x [batch, c_in, inner], y [batch, c_out, inner]; in_bias / out_bias may be NULL; in_act / out_act switch the
+ * activations.  The caller runs the preceding convolution without its bias and passes that bias as in_bias.
+ * Matrix path: fp16 split-half operands (hi + lo 2^-11, fp32 accumulation, 3 instructions per product); values beyond
+ * +-65504 are clamped and counted in sat_count (device int32, may be NULL).  wpack: vcnf_conv1x1_pack_floats(c_in, c_out)
+ * floats = W as A fragments of v_mfma_f32_32x32x16_f16, [8 row blocks][c_in / 16][hi | lo][64 lanes][8 halves]
+ * (vcnf_amd/nets/cnn.py::pack_conv1x1).  c_in multiple of 16 up to 256, c_out up to 256. */
+int vcnf_conv1x1_supported(int32_t c_in, int32_t c_out);
+int64_t vcnf_conv1x1_pack_floats(int32_t c_in, int32_t c_out);
+int vcnf_conv1x1_f16x3_f32(const float* x, float* y, const float* wpack, int64_t wpack_floats,
+                           const float* in_bias, const float* out_bias, int64_t batch, int32_t c_in, int32_t c_out,
+                           int64_t inner, int in_act, float in_slope, int out_act, float out_slope,
+                           int32_t* sat_count, void* stream);
+
 /* Identity half of one RQS coupling layer in one launch (coupling.py:76-116): for f < d_id and v = x[b, identity_idx[f]]
  *   y = S_f(v) (inverse = 0) or S_f^-1(v) (inverse = 1) with the batch-shared unconditional spline of feature f
  *       (PiecewiseRationalQuadraticCDF, coupling.py:165-246), or y = v when shared_w/h/d are all NULL;

@@ -884,6 +884,61 @@ def test_channel_mix_kernel(hip, c, h, w):
         _lib.channel_mix(torch.randn(2, 6, 2, 2, device="cuda"), torch.eye(6, device="cuda"), torch.zeros(6, device="cuda"))
 
 
+@pytest.mark.parametrize("c_in,c_out,h,w", [(256, 256, 16, 16), (256, 256, 4, 4), (64, 48, 3, 5), (16, 7, 1, 1), (96, 256, 2, 2)])
+def test_conv1x1_fused_kernel(hip, c_in, c_out, h, w):
+    """csrc/conv1x1.hip: y = leaky(W leaky(x + b_in) + b_out) in one pass on the fp16 split-half matrix path, against
+    fp64 beside torch's own fp32 composition (conv2d + bias + LeakyReLU kernels, nets/cnn.py:20-52); ragged pixel counts
+    (64-pixel passes cross image boundaries), partial row blocks (c_out not a multiple of 32), with and without the
+    optional biases / activations."""
+    from vcnf_amd.nets.cnn import pack_conv1x1
+    g = torch.Generator().manual_seed(c_in + c_out + h)
+    wgt = (torch.randn(c_out, c_in, generator=g) / c_in ** 0.5).cuda()
+    b_in, b_out = torch.randn(c_in, generator=g).cuda(), torch.randn(c_out, generator=g).cuda()
+    pack = pack_conv1x1(wgt)
+    assert pack.numel() == int(_lib.lib().vcnf_conv1x1_pack_floats(c_in, c_out))
+    lrelu = torch.nn.functional.leaky_relu
+    for b in (1, 3, 130):
+        x = torch.randn(b, c_in, h, w, generator=g).cuda()
+        for bi, bo, si, so in ((b_in, b_out, 0.0, 0.0), (b_in, b_out, 0.1, 0.2), (None, None, None, None), (None, b_out, None, 0.0)):
+            got = _lib.conv1x1_fused(x, pack, c_out, in_bias=bi, out_bias=bo, in_slope=si, out_slope=so)
+
+            def ref(xx, ww, dt):
+                t = xx.to(dt) + (bi.to(dt).view(1, -1, 1, 1) if bi is not None else 0)
+                t = lrelu(t, si) if si is not None else t
+                t = torch.einsum("oc,bchw->bohw", ww.to(dt), t) + (bo.to(dt).view(1, -1, 1, 1) if bo is not None else 0)
+                return lrelu(t, so) if so is not None else t
+            r64, r32 = ref(x, wgt, torch.float64), ref(x, wgt, torch.float32)
+            scale = float(r64.abs().max())
+            e_got, e_ref = float((got.double() - r64).abs().max()), float((r32.double() - r64).abs().max())
+            assert got.shape == r64.shape and e_got <= 2.0 * e_ref + 2e-6 * scale, (c_in, c_out, b, e_got, e_ref)
+    assert nf.check_saturation() == 0
+
+
+def test_convnet2d_fused_middle_layer(hip):
+    """ConvNet2d (Glow conditioner, nets/cnn.py:20-52) with its 1x1 convolution, both LeakyReLUs and two bias adds on
+    csrc/conv1x1.hip against the same module evaluated layer by layer, and the .data / refresh_packed contract."""
+    torch.manual_seed(9)
+    net = nf.nets.ConvNet2d((6, 256, 256, 12), (3, 1, 3), leaky=0.1, init_zeros=False).cuda().eval()
+    x = torch.randn(37, 6, 8, 8, device="cuda")
+    with torch.no_grad():
+        assert net._fusable(x)
+        got = net(x)
+        net.fused_conv1x1 = False
+        ref = net(x)
+        ref64 = net.double()(x.double())
+        net.float()
+        net.fused_conv1x1 = True
+        e_got, e_ref = float((got.double() - ref64).abs().max()), float((ref.double() - ref64).abs().max())
+        assert e_got <= 2.0 * e_ref + 2e-6 * float(ref64.abs().max()), (e_got, e_ref)
+        # (not bitwise below: the library's 3x3 convolutions are not run-to-run deterministic)
+        assert float((net(x) - got).abs().max()) <= 1e-5   # re-packed: .double() / .float() moved the parameters
+        net.net[2].weight.data.mul_(0.5)
+        assert float((net(x) - got).abs().max()) <= 1e-5   # packed copy keyed on (data_ptr, _version): stale
+        nf.refresh_packed(net)
+        assert float((net(x) - got).abs().max()) > 1e-3
+    assert not net._fusable(x.requires_grad_(True)) or not torch.is_grad_enabled()
+
+
 @pytest.mark.parametrize("use_lu", [True, False])
 def test_glow_block_fused_mixers_match_layerwise(hip, use_lu):
     """GlowBlock with the 1x1 convolution and ActNorm composed into one channel map (vcnf_amd/flows/affine/glow.py)

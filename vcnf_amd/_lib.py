@@ -58,6 +58,9 @@ PROTOTYPES = {
                                ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P], _INT),
     "vcnf_rqs_conditioner_input_f32": ([_P, _I64, _I32, _P, _I32, _P, _I32, _P, _P, _P,
                                         ctypes.POINTER(RqsCfg), _INT, _P, _P], _INT),
+    "vcnf_conv1x1_supported": ([_I32, _I32], _INT),
+    "vcnf_conv1x1_pack_floats": ([_I32, _I32], _I64),
+    "vcnf_conv1x1_f16x3_f32": ([_P, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _I64, _INT, _F32, _INT, _F32, _P, _P], _INT),
     "vcnf_channel_mix_supported": ([_I32], _INT),
     "vcnf_channel_mix_f32": ([_P, _P, _P, _P, _I64, _I32, _I64, _P], _INT),
     "vcnf_rqs_identity_half_supported": ([_I32, _I32], _INT),
@@ -264,6 +267,8 @@ def check_saturation(device="cuda", model=None):
         for m in model.modules():
             if hasattr(m, "fused_precision"):
                 m.fused_precision = "fp32"
+            if hasattr(m, "fused_conv1x1"):           # ConvNet2d: back to the library's fp32 1x1 convolution
+                m.fused_conv1x1 = False
     return n
 
 
@@ -671,6 +676,23 @@ def affine_const(z, s, t, inverse):
         st = lib().vcnf_affine_const_f32(_ptr(z), _ptr(s), _ptr(t), _ptr(out), b, c, inner,
                                          int(bool(inverse)), _stream())
     _check(st, "vcnf_affine_const_f32")
+    return out
+
+
+def conv1x1_fused(x, wpack, c_out, in_bias=None, out_bias=None, in_slope=None, out_slope=None):
+    """act_out(W act_in(x + in_bias) + out_bias) for NCHW x in one pass (csrc/conv1x1.hip, fp16 split-half matrix path);
+    a slope of None switches that LeakyReLU off."""
+    dev = require_device(x, wpack, in_bias, out_bias)
+    x = x.contiguous()
+    b, c_in = x.shape[0], x.shape[1]
+    inner = int(x[0, 0].numel())
+    out = torch.empty((b, c_out) + tuple(x.shape[2:]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("conv1x1_fused"):
+        st = lib().vcnf_conv1x1_f16x3_f32(_ptr(x), _ptr(out), _ptr(wpack), wpack.numel(), _ptr(in_bias), _ptr(out_bias),
+                                          b, int(c_in), int(c_out), inner, int(in_slope is not None),
+                                          float(in_slope or 0.0), int(out_slope is not None), float(out_slope or 0.0),
+                                          _ptr(saturation_counter(dev)), _stream())
+    _check(st, "vcnf_conv1x1_f16x3_f32")
     return out
 
 

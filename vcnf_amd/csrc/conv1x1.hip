@@ -1,0 +1,193 @@
+// 1x1 convolution of an NCHW batch with its neighbouring bias adds and LeakyReLUs in ONE pass:
+//     y[b, o, p] = act_out( sum_c W[o, c] act_in(x[b, c, p] + in_bias[c]) + out_bias[o] )
+// This is the middle layer of Glow's coupling conditioner (nets/cnn.py:20-52: Conv3x3, LeakyReLU, Conv1x1, LeakyReLU,
+// Conv3x3; flows/affine/glow.py:37-47) together with the bias + LeakyReLU that follow the first convolution and the
+// bias + LeakyReLU that follow the 1x1 convolution: the caller runs the first 3x3 convolution WITHOUT its bias, this
+// kernel applies that bias and activation on load and its own on store, and the hidden activations (256 channels:
+// 64 x the coupling's own data) cross HBM twice instead of ten times (library convolution + 2 bias kernels + 2
+// activation kernels, each a read and a write).
+//
+// A dense contraction over the channels, so it runs on the matrix cores: v_mfma_f32_32x32x16_f16 with both operands
+// split into hi + lo * 2^-11 fp16 halves (22 significant bits, 3 instructions per product, fp32 accumulation - the
+// scheme of fused_layer_v6.hip; values beyond +-65504 are clamped and counted in `sat`).
+//   * workgroup = 8 waves; wave w owns output channels 32 w .. 32 w + 31 and keeps ITS weight fragments (hi and lo for
+//     every k-step: <= 128 registers) for the whole launch - no weight traffic after the prologue;
+//   * a pass handles 64 pixels (two 32-column blocks): every thread loads 8 consecutive input channels of one pixel
+//     (lanes = consecutive pixels: coalesced rows), applies bias + activation, splits, and writes one 16-byte
+//     B-fragment entry (hi) and one (lo) into LDS; after a barrier every wave runs, per 32-pixel column block, three
+//     independent accumulator chains (hi x hi, hi x lo, lo x hi) over the k-steps on the LDS fragments and stores its
+//     32 channels x 32 pixels (128-byte rows).
+// C_in multiple of 16 up to 256, C_out up to 256.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vcnf_hip.h"
+#include "fused_common.hpp"
+
+namespace vcnf {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct Conv1Args {
+  const float* x;
+  float* y;
+  const uint4* wfrag;      // [8 row blocks][KS][hi | lo][64 lanes] 16-byte fragments
+  const float* in_bias;    // [C_in] or null
+  const float* out_bias;   // [C_out] or null
+  long long npix, inner;
+  int Cin, Cout, in_act, out_act;
+  float in_slope, out_slope;
+  int32_t* sat;
+};
+
+constexpr int kC1Block = 512;
+constexpr int kC1Pix = 64;
+
+template <int KS>
+__global__ __launch_bounds__(kC1Block, 2) void conv1x1_f16x3_kernel(const Conv1Args a) {
+  extern __shared__ __align__(16) uint4 bfrag[];        // [KS][2 column blocks][hi | lo][64 lanes]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool active = wave * 32 < a.Cout;
+  half8 wh[KS], wl[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    wh[ks] = __builtin_bit_cast(half8, a.wfrag[((wave * KS + ks) * 2 + 0) * 64 + lane]);
+    wl[ks] = __builtin_bit_cast(half8, a.wfrag[((wave * KS + ks) * 2 + 1) * 64 + lane]);
+  }
+  const int px = tid & 63;            // loader role: pixel of the pass, channel groups kq, kq + 8, ...
+  const int kq = tid >> 6;
+  float satm = 0.f;
+  const long long ntiles = (a.npix + kC1Pix - 1) / kC1Pix;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    {
+      const long long g = tile * kC1Pix + px;
+      const bool ok = g < a.npix;
+      const long long b = ok ? g / a.inner : 0;
+      const float* src = a.x + b * a.Cin * a.inner + (ok ? g - b * a.inner : 0);
+      __syncthreads();                 // the previous pass's fragments are consumed
+      for (int cg = kq; cg < 2 * KS; cg += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = ok ? src[(long long)(8 * cg + i) * a.inner] : 0.f;
+        half8 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float t = v[i];
+          if (a.in_bias) t += a.in_bias[8 * cg + i];
+          if (a.in_act) t = t >= 0.f ? t : t * a.in_slope;
+          satm = fmaxf(satm, __builtin_fabsf(t));
+          t = __builtin_amdgcn_fmed3f(t, -65504.f, 65504.f);
+          const _Float16 h = (_Float16)t;
+          hi[i] = h;
+          lo[i] = (_Float16)((t - (float)h) * kLoScale);
+        }
+        const int ks = cg >> 1, ln = 32 * (cg & 1) + (px & 31), ct = px >> 5;
+        bfrag[((ks * 2 + ct) * 2 + 0) * 64 + ln] = __builtin_bit_cast(uint4, hi);
+        bfrag[((ks * 2 + ct) * 2 + 1) * 64 + ln] = __builtin_bit_cast(uint4, lo);
+      }
+      __syncthreads();
+    }
+    if (active) {
+      // one 32-pixel column block at a time: three independent accumulator chains (main, hi x lo, lo x hi)
+#pragma unroll 1
+      for (int ct = 0; ct < 2; ++ct) {
+        floatx16 mainv, ca, cb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { mainv[r] = 0.f; ca[r] = 0.f; cb[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const half8 bh = __builtin_bit_cast(half8, bfrag[((ks * 2 + ct) * 2 + 0) * 64 + lane]);
+          const half8 bl = __builtin_bit_cast(half8, bfrag[((ks * 2 + ct) * 2 + 1) * 64 + lane]);
+          mainv = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], bh, mainv, 0, 0, 0);
+          ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], bl, ca, 0, 0, 0);
+          cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], bh, cb, 0, 0, 0);
+        }
+        const long long g = tile * kC1Pix + 32 * ct + (lane & 31);
+        if (g < a.npix) {
+          const long long b = g / a.inner;
+          float* dst = a.y + b * a.Cout * a.inner + (g - b * a.inner);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = 32 * wave + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            if (row < a.Cout) {
+              float t = fmaf(ca[r] + cb[r], kLoUnscale, mainv[r]);
+              if (a.out_bias) t += a.out_bias[row];
+              if (a.out_act) t = t >= 0.f ? t : t * a.out_slope;
+              dst[(long long)row * a.inner] = t;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (a.sat && satm > 65504.f) atomicAdd(a.sat, 1);
+}
+
+template <int KS>
+static int launch_conv1(const Conv1Args& a, hipStream_t st) {
+  const size_t lds = (size_t)KS * 2 * 2 * 64 * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_f16x3_kernel<KS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return VCNF_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const long long ntiles = (a.npix + kC1Pix - 1) / kC1Pix;
+  const long long cap = 256 * 2;
+  dim3 grid((unsigned)(ntiles < cap ? ntiles : cap));
+  hipLaunchKernelGGL((conv1x1_f16x3_kernel<KS>), grid, dim3(kC1Block), lds, st, a);
+  return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
+}
+
+}  // namespace vcnf
+
+using namespace vcnf;
+
+extern "C" int vcnf_conv1x1_supported(int32_t c_in, int32_t c_out) {
+  return (c_in >= 16 && c_in <= 256 && c_in % 16 == 0 && c_out >= 1 && c_out <= 256) ? 1 : 0;
+}
+
+extern "C" int64_t vcnf_conv1x1_pack_floats(int32_t c_in, int32_t c_out) {
+  if (!vcnf_conv1x1_supported(c_in, c_out)) return 0;
+  return (int64_t)8 * (c_in / 16) * 2 * 64 * 4;
+}
+
+extern "C" int vcnf_conv1x1_f16x3_f32(const float* x, float* y, const float* wpack, int64_t wpack_floats,
+                                      const float* in_bias, const float* out_bias, int64_t batch, int32_t c_in,
+                                      int32_t c_out, int64_t inner, int in_act, float in_slope, int out_act,
+                                      float out_slope, int32_t* sat_count, void* stream) {
+  if (!vcnf_conv1x1_supported(c_in, c_out)) return VCNF_ERR_UNSUPPORTED;
+  if (batch < 0 || inner < 1) return VCNF_ERR_SHAPE;
+  if (wpack_floats != vcnf_conv1x1_pack_floats(c_in, c_out)) return VCNF_ERR_SHAPE;
+  if (batch == 0) return VCNF_OK;
+  if (!x || !y || !wpack) return VCNF_ERR_NULL;
+  if (reinterpret_cast<uintptr_t>(wpack) & 15) return VCNF_ERR_ALIGN;
+  Conv1Args a;
+  a.x = x; a.y = y; a.wfrag = reinterpret_cast<const uint4*>(wpack); a.in_bias = in_bias; a.out_bias = out_bias;
+  a.npix = batch * inner; a.inner = inner; a.Cin = c_in; a.Cout = c_out;
+  a.in_act = in_act ? 1 : 0; a.out_act = out_act ? 1 : 0; a.in_slope = in_slope; a.out_slope = out_slope;
+  a.sat = sat_count;
+  hipStream_t st = (hipStream_t)stream;
+  switch (c_in / 16) {
+    case 1: return launch_conv1<1>(a, st);
+    case 2: return launch_conv1<2>(a, st);
+    case 3: return launch_conv1<3>(a, st);
+    case 4: return launch_conv1<4>(a, st);
+    case 5: return launch_conv1<5>(a, st);
+    case 6: return launch_conv1<6>(a, st);
+    case 7: return launch_conv1<7>(a, st);
+    case 8: return launch_conv1<8>(a, st);
+    case 9: return launch_conv1<9>(a, st);
+    case 10: return launch_conv1<10>(a, st);
+    case 11: return launch_conv1<11>(a, st);
+    case 12: return launch_conv1<12>(a, st);
+    case 13: return launch_conv1<13>(a, st);
+    case 14: return launch_conv1<14>(a, st);
+    case 15: return launch_conv1<15>(a, st);
+    case 16: return launch_conv1<16>(a, st);
+    default: return VCNF_ERR_UNSUPPORTED;
+  }
+}

@@ -1,7 +1,10 @@
-"""Convolutional conditioner of the Glow blocks (callee of the hot path; the convolutions
-run on PyTorch-ROCm / MIOpen).  Reference: normflow/nets/cnn.py:7-46; state-dict layout
+"""Convolutional conditioner of the Glow blocks (callee of the hot path).  The 3x3 convolutions run on
+PyTorch-ROCm / MIOpen; at inference the 1x1 convolution in the middle runs on csrc/conv1x1.hip fused with the bias
+adds and LeakyReLUs on both sides of it (ConvNet2d.forward).  Reference: normflow/nets/cnn.py:7-46; state-dict layout
 ``net.{i}.weight|bias`` with convolutions at even positions."""
+import torch
 from torch import nn
+from torch.nn import functional as F
 
 
 class ConvNet2d(nn.Module):
@@ -26,5 +29,67 @@ class ConvNet2d(nn.Module):
         mods.append(last)
         self.net = nn.Sequential(*mods)
 
+    # ------------------------------------------------------------------ inference: fused middle layer
+    fused_conv1x1 = True
+
+    def _fusable(self, x):
+        """Conv(k) , LeakyReLU, Conv(1x1), LeakyReLU, Conv(k) on a CUDA fp32 batch without autograd: the 1x1 convolution
+        runs on csrc/conv1x1.hip together with the first convolution's bias, both activations and its own bias."""
+        from .. import _lib, autograd
+        mods = list(self.net)
+        if not (self.fused_conv1x1 and len(mods) == 5 and x.dim() == 4 and x.is_cuda and x.dtype == torch.float32):
+            return False
+        c1, a1, c2, a2, c3 = mods
+        if not (isinstance(c1, nn.Conv2d) and isinstance(c2, nn.Conv2d) and isinstance(c3, nn.Conv2d)
+                and isinstance(a1, nn.LeakyReLU) and isinstance(a2, nn.LeakyReLU)):
+            return False
+        if c2.kernel_size != (1, 1) or c2.stride != (1, 1) or c2.groups != 1 or c2.dilation != (1, 1) or c2.padding != (0, 0):
+            return False
+        if torch.is_grad_enabled() and autograd.needs_grad(x, *self.parameters()):
+            return False
+        return bool(_lib.lib().vcnf_conv1x1_supported(c2.in_channels, c2.out_channels))
+
+    def _packed_conv1x1(self):
+        c2 = self.net[2]
+        key = (c2.weight.data_ptr(), c2.weight._version, str(c2.weight.device))
+        cache = self.__dict__.setdefault('_fused_conv_pack', {})
+        if cache.get('key') != key:
+            with torch.no_grad():
+                buf = pack_conv1x1(c2.weight.detach().view(c2.out_channels, c2.in_channels))
+            old = cache.get('buf')
+            if old is not None and old.shape == buf.shape and old.device == buf.device:
+                old.copy_(buf)           # in place: a captured HIP graph keeps reading this address
+            else:
+                cache['buf'] = buf
+            cache['key'] = key
+        return cache['buf']
+
     def forward(self, x):
+        if self._fusable(x):
+            from .. import _lib
+            c1, a1, c2, a2, c3 = self.net
+            h = F.conv2d(x, c1.weight, None, c1.stride, c1.padding, c1.dilation, c1.groups)     # bias applied below
+            h = _lib.conv1x1_fused(h, self._packed_conv1x1(), c2.out_channels, in_bias=c1.bias, out_bias=c2.bias,
+                                   in_slope=float(a1.negative_slope), out_slope=float(a2.negative_slope))
+            return c3(h)
         return self.net(x)
+
+
+def pack_conv1x1(w):
+    """W [c_out, c_in] -> A fragments of v_mfma_f32_32x32x16_f16 for csrc/conv1x1.hip: [8 row blocks][c_in / 16]
+    [hi | lo][64 lanes][8 halves], lane l holding row 32 rb + l % 32, input channels 16 ks + 8 (l / 32) + i; rows beyond
+    c_out are zero; hi / lo = the fp16 split of fused._split_halves (w ~ hi + lo / 2048)."""
+    from ..fused import _split_halves, _as_floats
+    c_out, c_in = w.shape
+    dev = w.device
+    rb = torch.arange(8, device=dev).view(-1, 1, 1, 1)
+    ks = torch.arange(c_in // 16, device=dev).view(1, -1, 1, 1)
+    lane = torch.arange(64, device=dev).view(1, 1, -1, 1)
+    i = torch.arange(8, device=dev).view(1, 1, 1, -1)
+    shape = (8, c_in // 16, 64, 8)
+    rows = (32 * rb + (lane & 31)).expand(shape)
+    cols = (16 * ks + 8 * (lane >> 5) + i).expand(shape)
+    ok = rows < c_out
+    vals = torch.where(ok, w[torch.where(ok, rows, torch.zeros_like(rows)), cols], torch.zeros((), device=dev, dtype=w.dtype))
+    hi, lo = _split_halves(vals)                                   # [8, ks, 64, 8]
+    return _as_floats(torch.stack([hi, lo], dim=2)).contiguous()   # [8, ks, 2, 64, 8]
