@@ -60,35 +60,49 @@ __global__ __launch_bounds__(kC1Block, 2) void conv1x1_f16x3_kernel(const Conv1A
   const int kq = tid >> 6;
   float satm = 0.f;
   const long long ntiles = (a.npix + kC1Pix - 1) / kC1Pix;
+  // a thread's share of a pass: NIT groups of 8 input channels of its pixel, requested two groups at a time (16 rows
+  // in flight per thread; all four at once, or the next pass during the matrix phase, spill 48 / 84 registers at
+  // C_in = 256 on top of the 128 weight registers)
+  constexpr int NIT = (2 * KS + 7) / 8;
+  constexpr int NCH = NIT > 2 ? 2 : NIT;             // groups requested together
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    {
-      const long long g = tile * kC1Pix + px;
-      const bool ok = g < a.npix;
-      const long long b = ok ? g / a.inner : 0;
-      const float* src = a.x + b * a.Cin * a.inner + (ok ? g - b * a.inner : 0);
-      __syncthreads();                 // the previous pass's fragments are consumed
-      for (int cg = kq; cg < 2 * KS; cg += 8) {
-        float v[8];
+    const long long g = tile * kC1Pix + px;
+    const bool ok = g < a.npix;
+    const long long b = ok ? g / a.inner : 0;
+    const float* src = a.x + b * a.Cin * a.inner + (ok ? g - b * a.inner : 0);
+    __syncthreads();                 // the previous pass's fragments are consumed
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += NCH) {
+      float v[NCH][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = ok ? src[(long long)(8 * cg + i) * a.inner] : 0.f;
-        half8 hi, lo;
+      for (int u = 0; u < NCH; ++u) {
+        const int cg = kq + 8 * (it0 + u);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float t = v[i];
-          if (a.in_bias) t += a.in_bias[8 * cg + i];
-          if (a.in_act) t = t >= 0.f ? t : t * a.in_slope;
-          satm = fmaxf(satm, __builtin_fabsf(t));
-          t = __builtin_amdgcn_fmed3f(t, -65504.f, 65504.f);
-          const _Float16 h = (_Float16)t;
-          hi[i] = h;
-          lo[i] = (_Float16)((t - (float)h) * kLoScale);
-        }
-        const int ks = cg >> 1, ln = 32 * (cg & 1) + (px & 31), ct = px >> 5;
-        bfrag[((ks * 2 + ct) * 2 + 0) * 64 + ln] = __builtin_bit_cast(uint4, hi);
-        bfrag[((ks * 2 + ct) * 2 + 1) * 64 + ln] = __builtin_bit_cast(uint4, lo);
+        for (int i = 0; i < 8; ++i) v[u][i] = (ok && cg < 2 * KS) ? src[(long long)(8 * cg + i) * a.inner] : 0.f;
       }
-      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < NCH; ++u) {
+        const int cg = kq + 8 * (it0 + u);
+        if (it0 + u < NIT && cg < 2 * KS) {
+          half8 hi, lo;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float t = v[u][i];
+            if (a.in_bias) t += a.in_bias[8 * cg + i];
+            if (a.in_act) t = t >= 0.f ? t : t * a.in_slope;
+            satm = fmaxf(satm, __builtin_fabsf(t));
+            t = __builtin_amdgcn_fmed3f(t, -65504.f, 65504.f);
+            const _Float16 h = (_Float16)t;
+            hi[i] = h;
+            lo[i] = (_Float16)((t - (float)h) * kLoScale);
+          }
+          const int ks = cg >> 1, ln = 32 * (cg & 1) + (px & 31), ct = px >> 5;
+          bfrag[((ks * 2 + ct) * 2 + 0) * 64 + ln] = __builtin_bit_cast(uint4, hi);
+          bfrag[((ks * 2 + ct) * 2 + 1) * 64 + ln] = __builtin_bit_cast(uint4, lo);
+        }
+      }
     }
+    __syncthreads();
     if (active) {
       // one 32-pixel column block at a time: three independent accumulator chains (main, hi x lo, lo x hi)
 #pragma unroll 1
