@@ -232,6 +232,18 @@ int vcnf_conv1x1_f16x3_f32(const float* x, float* y, const float* wpack, int64_t
                            int64_t inner, int in_act, float in_slope, int out_act, float out_slope,
                            int32_t* sat_count, void* stream);
 
+/* Weight and bias gradient of a dense conditioner layer y = x W^T + b for large batches (training path; the reference
+ * gets them from autograd over nets/resnet.py:92-106):  dw[o, i] (+)= sum_b dy[b, o] x[b, i],  db[o] (+)= sum_b dy[b, o]
+ * with x [batch, in_features], dy [batch, out_features] row-major; db may be NULL.  The reduction over the batch is
+ * split into vcnf_linear_wgrad_slices(...) slices (exact fp32 matrix instructions), whose partial results go through
+ * `workspace` (>= slices * (out * in + out) floats) and are added in a fixed order.  accumulate != 0 adds to dw / db.
+ * in_features: multiple of 16 up to 128. */
+int vcnf_linear_wgrad_supported(int32_t in_features, int32_t out_features);
+int64_t vcnf_linear_wgrad_slices(int64_t batch, int32_t in_features, int32_t out_features);
+int vcnf_linear_wgrad_f32(const float* x, const float* dy, float* dw, float* db, float* workspace,
+                          int64_t workspace_floats, int64_t batch, int32_t in_features, int32_t out_features,
+                          int accumulate, void* stream);
+
 /* Identity half of one RQS coupling layer in one launch (coupling.py:76-116): for f < d_id and v = x[b, identity_idx[f]]
  *   y = S_f(v) (inverse = 0) or S_f^-1(v) (inverse = 1) with the batch-shared unconditional spline of feature f
  *       (PiecewiseRationalQuadraticCDF, coupling.py:165-246), or y = v when shared_w/h/d are all NULL;

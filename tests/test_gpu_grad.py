@@ -377,3 +377,52 @@ def test_image_rqs_coupling_gradients(hip):
         ofn = "nsf_forward" if dirn == "forward" else "nsf_inverse"
         _grad_compare(getattr(m, dirn), lambda s, x, c: getattr(oracle_image_rqs_coupling(s), ofn)(x, c), sd,
                       [T(fx["x"]), T(fx["ctx"])], "image rqs " + dirn, loss_of=pick)
+
+@pytest.mark.parametrize("n_in,n_out,b", [(128, 128, 16384 + 37), (48, 128, 8192), (16, 128, 9000), (128, 736, 10000), (64, 5, 300)])
+def test_linear_wgrad_kernel(hip, n_in, n_out, b):
+    """csrc/linear_wgrad.hip: dW = dy^T x and db = sum dy with the batch reduction split over the chip, against fp64
+    beside torch's own fp32 GEMM / column sum (the reference's autograd path, nets/resnet.py:92-106); ragged batches,
+    partial row tiles (OUT not a multiple of 128 / 32)."""
+    from vcnf_amd import _lib
+    g = torch.Generator().manual_seed(n_in + n_out)
+    x = torch.randn(b, n_in, generator=g).cuda()
+    dy = torch.randn(b, n_out, generator=g).cuda()
+    dw, db = _lib.linear_wgrad(x, dy)
+    w64, b64 = dy.double().t() @ x.double(), dy.double().sum(0)
+    w32, b32 = dy.t() @ x, dy.sum(0)
+    for got, r64, r32, what in ((dw, w64, w32, "dW"), (db, b64, b32, "db")):
+        e_got, e_ref = float((got.double() - r64).abs().max()), float((r32.double() - r64).abs().max())
+        assert got.shape == r64.shape and e_got <= 2.0 * e_ref + 1e-6 * float(r64.abs().max()), (what, e_got, e_ref)
+    dw2, none = _lib.linear_wgrad(x, dy, want_bias=False)
+    assert none is None and torch.equal(dw2, dw)                     # deterministic
+
+
+def test_resnet_training_uses_wgrad_kernel_and_matches_autograd(hip):
+    """ResidualNet at a training batch size: the dense layers' weight / bias gradients come from the weight-gradient
+    kernel (vcnf_amd/autograd.py::LinearFn) and equal PyTorch's own autograd of the same network to rounding."""
+    from vcnf_amd import _lib, autograd
+    torch.manual_seed(3)
+    net = nf.nets.ResidualNet(48, 96, 128, context_features=16, num_blocks=2).cuda()
+    x = torch.randn(8192 + 5, 48, device="cuda")
+    ctx = torch.randn(8192 + 5, 16, device="cuda")
+    up = torch.randn(8192 + 5, 96, device="cuda")
+
+    def grads(min_batch):
+        old = autograd.WGRAD_MIN_BATCH
+        autograd.WGRAD_MIN_BATCH = min_batch
+        try:
+            net.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_(True)
+            events = []
+            _lib.EVENT_SINK = events
+            (net(xi, ctx) * up).sum().backward()
+            _lib.EVENT_SINK = None
+            return [xi.grad] + [p.grad.clone() for p in net.parameters()], len([e for e in events if e[2] == "linear_wgrad"])
+        finally:
+            autograd.WGRAD_MIN_BATCH = old
+    mine, launches = grads(8192)
+    ref, none = grads(1 << 40)
+    assert launches == 1 + 2 * 2 + 2 + 1 and none == 0                # initial, 2 x 2 block layers, 2 context layers, final
+    for a, b in zip(mine, ref):
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-6
+

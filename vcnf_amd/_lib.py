@@ -61,6 +61,9 @@ PROTOTYPES = {
     "vcnf_conv1x1_supported": ([_I32, _I32], _INT),
     "vcnf_conv1x1_pack_floats": ([_I32, _I32], _I64),
     "vcnf_conv1x1_f16x3_f32": ([_P, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _I64, _INT, _F32, _INT, _F32, _P, _P], _INT),
+    "vcnf_linear_wgrad_supported": ([_I32, _I32], _INT),
+    "vcnf_linear_wgrad_slices": ([_I64, _I32, _I32], _I64),
+    "vcnf_linear_wgrad_f32": ([_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _INT, _P], _INT),
     "vcnf_channel_mix_supported": ([_I32], _INT),
     "vcnf_channel_mix_f32": ([_P, _P, _P, _P, _I64, _I32, _I64, _P], _INT),
     "vcnf_rqs_identity_half_supported": ([_I32, _I32], _INT),
@@ -694,6 +697,34 @@ def conv1x1_fused(x, wpack, c_out, in_bias=None, out_bias=None, in_slope=None, o
                                           _ptr(saturation_counter(dev)), _stream())
     _check(st, "vcnf_conv1x1_f16x3_f32")
     return out
+
+
+_WGRAD_WS = {}
+
+
+def linear_wgrad(x, dy, want_bias=True):
+    """(dW [out, in], db [out] or None) of y = x W^T + b from x [B, in] and dy [B, out] (csrc/linear_wgrad.hip: the batch
+    reduction split over the chip, exact fp32 matrix instructions, deterministic)."""
+    dev = require_device(x, dy, allow_grad=True)
+    x, dy = x.detach().contiguous(), dy.detach().contiguous()
+    b, n_in = x.shape
+    n_out = dy.shape[1]
+    slices = int(lib().vcnf_linear_wgrad_slices(b, n_in, n_out))
+    if slices < 1:
+        raise VcnfError("linear_wgrad: unsupported layer shape %d -> %d" % (n_in, n_out))
+    need = slices * (n_out * n_in + n_out)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=dev)
+        _WGRAD_WS[key] = ws
+    dw = torch.empty(n_out, n_in, dtype=torch.float32, device=dev)
+    db = torch.empty(n_out, dtype=torch.float32, device=dev) if want_bias else None
+    with torch.cuda.device(dev), _timed("linear_wgrad"):
+        st = lib().vcnf_linear_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), b, int(n_in),
+                                         int(n_out), 0, _stream())
+    _check(st, "vcnf_linear_wgrad_f32")
+    return dw, db
 
 
 def channel_mix(z, matrix, shift):

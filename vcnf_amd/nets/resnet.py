@@ -3,11 +3,14 @@
 Same parameter names as the reference (``initial_layer``, ``blocks.{i}.
 linear_layers.{0,1}``, ``blocks.{i}.context_layer``, ``final_layer``) so its
 checkpoints load unchanged.  Reference: normflow/nets/resnet.py:8-106.
-The dense layers are plain GEMMs on PyTorch-ROCm (MFMA through hipBLASLt).
+The dense layers are plain GEMMs on PyTorch-ROCm (MFMA through hipBLASLt); at training batch sizes their weight /
+bias gradients come from csrc/linear_wgrad.hip (autograd.linear).
 """
 import torch
 from torch import nn
 from torch.nn import functional as F
+
+from ..autograd import linear as _linear
 
 
 class ResidualBlock(nn.Module):
@@ -38,9 +41,9 @@ class ResidualBlock(nn.Module):
             h = self.activation(h)
             if i == 1:
                 h = self.dropout(h)
-            h = self.linear_layers[i](h)
+            h = _linear(self.linear_layers[i], h)
         if context is not None:
-            h = F.glu(torch.cat((h, self.context_layer(context)), dim=1), dim=1)
+            h = F.glu(torch.cat((h, _linear(self.context_layer, context)), dim=1), dim=1)
         return inputs + h
 
 
@@ -72,7 +75,7 @@ class ResidualNet(nn.Module):
         """Output of the last residual block (the input of ``final_layer``) for an already
         concatenated (identity | context) input; the last layer itself can then run inside the
         spline kernel (csrc/fused_final.hip)."""
-        h = self.initial_layer(first_in)
+        h = _linear(self.initial_layer, first_in)
         for block in self.blocks:
             h = block(h, context=context)
         return h
@@ -80,10 +83,10 @@ class ResidualNet(nn.Module):
     def trunk(self, first_in, context=None):
         """Everything after the (identity | context) concatenation; the RQS
         coupling calls this directly with the buffer its gather kernel wrote."""
-        h = self.initial_layer(first_in)
+        h = _linear(self.initial_layer, first_in)
         for block in self.blocks:
             h = block(h, context=context)
-        return self.final_layer(h)
+        return _linear(self.final_layer, h)
 
 
 class ConvResidualBlock(nn.Module):
