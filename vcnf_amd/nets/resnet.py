@@ -43,7 +43,13 @@ class ResidualBlock(nn.Module):
                 h = self.dropout(h)
             h = _linear(self.linear_layers[i], h)
         if context is not None:
-            h = F.glu(torch.cat((h, _linear(self.context_layer, context)), dim=1), dim=1)
+            gate = _linear(self.context_layer, context)
+            if torch.is_grad_enabled() and (h.requires_grad or gate.requires_grad) and h.shape[0] >= 32768:
+                # large training batches: glu(cat(h, gate)) = h * sigmoid(gate) without materialising the concatenation
+                # and its backward slices (resnet.py:54-56; same arithmetic; more, smaller launches: not for small batches)
+                h = h * torch.sigmoid(gate)
+            else:
+                h = F.glu(torch.cat((h, gate), dim=1), dim=1)
         return inputs + h
 
 
