@@ -237,6 +237,59 @@ __global__ __launch_bounds__(kBlock) void diag_gaussian_kernel(const GaussArgs a
   }
 }
 
+// Same arithmetic for D <= NC * G (a lane owns at most NC fixed columns): the per-column constants - and the exp()
+// of the scale - are computed once per lane instead of once per element (the loads from log_scale may alias the
+// outputs, so the compiler cannot hoist them out of the row loop above), and two rows are in flight per lane group.
+// 1M x 64: 201 -> us per call (HBM floor 32 us).
+template <int NC>
+__global__ __launch_bounds__(kBlock) void diag_gaussian_cols_kernel(const GaussArgs a) {
+  const int g = threadIdx.x & (a.G - 1);
+  const int per_block = kBlock / a.G;
+  float ls[NC], sc[NC], lc[NC];
+  bool have[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int j = g + c * a.G;
+    have[c] = j < a.D;
+    ls[c] = have[c] ? a.log_scale[j] + a.log_temp : 0.f;
+    sc[c] = expf(ls[c]);
+    lc[c] = have[c] ? a.loc[j] : 0.f;
+  }
+  const long long step = (long long)gridDim.x * per_block;
+  for (long long r = (long long)blockIdx.x * per_block + threadIdx.x / a.G; r < a.B; r += 2 * step) {
+    const long long r2 = r + step;
+    const bool two = r2 < a.B;
+    float v0[NC], v1[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      v0[c] = have[c] ? a.in[r * a.D + g + c * a.G] : 0.f;
+      v1[c] = (have[c] && two) ? a.in[r2 * a.D + g + c * a.G] : 0.f;
+    }
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (have[c]) {
+        if (a.sample) {
+          a.z[r * a.D + g + c * a.G] = lc[c] + sc[c] * v0[c];
+          if (two) a.z[r2 * a.D + g + c * a.G] = lc[c] + sc[c] * v1[c];
+          acc0 += ls[c] + 0.5f * v0[c] * v0[c];
+          acc1 += ls[c] + 0.5f * v1[c] * v1[c];
+        } else {
+          const float u0 = (v0[c] - lc[c]) / sc[c], u1 = (v1[c] - lc[c]) / sc[c];
+          acc0 += ls[c] + 0.5f * u0 * u0;
+          acc1 += ls[c] + 0.5f * u1 * u1;
+        }
+      }
+    }
+    acc0 = group_sum(acc0, a.G);
+    acc1 = group_sum(acc1, a.G);
+    if (g == 0) {
+      put_ld(a.logp, r, a.ld_sign * (a.norm - acc0), a.ld_mode);
+      if (two) put_ld(a.logp, r2, a.ld_sign * (a.norm - acc1), a.ld_mode);
+    }
+  }
+}
+
 static inline bool ok_ld(int m) { return m == VCNF_LD_STORE || m == VCNF_LD_ACCUM; }
 static inline int launched() { return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH; }
 
@@ -332,7 +385,16 @@ static int gauss(const float* in, const float* loc, const float* log_scale, floa
   if (!in || !loc || !log_scale || !logp || (sample && !z)) return VCNF_ERR_NULL;
   GaussArgs a{in, loc, log_scale, z, logp, batch, features, pick_lanes(features), ld_mode, sample,
               log_temperature, ld_sign, (float)(-0.5 * (double)features * log(2.0 * M_PI))};
-  hipLaunchKernelGGL(diag_gaussian_kernel, grid_for(batch, a.G), dim3(kBlock), 0, (hipStream_t)stream, a);
+  const int nc = (features + a.G - 1) / a.G;
+  const dim3 grid = grid_for(batch, a.G);
+  hipStream_t st = (hipStream_t)stream;
+  switch (nc) {
+    case 1: hipLaunchKernelGGL(diag_gaussian_cols_kernel<1>, grid, dim3(kBlock), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(diag_gaussian_cols_kernel<2>, grid, dim3(kBlock), 0, st, a); break;
+    case 3: hipLaunchKernelGGL(diag_gaussian_cols_kernel<3>, grid, dim3(kBlock), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(diag_gaussian_cols_kernel<4>, grid, dim3(kBlock), 0, st, a); break;
+    default: hipLaunchKernelGGL(diag_gaussian_kernel, grid, dim3(kBlock), 0, st, a); break;
+  }
   return launched();
 }
 
