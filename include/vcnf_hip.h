@@ -154,7 +154,7 @@ int vcnf_rqs_shared_bwd_f32(const float* x, const float* sw, const float* sh, co
  * transformed columns y[:, transform_idx] (the caller has filled the identity columns) and the
  * per-group-block log|det| rows partial[vcnf_rqs_final_fused_partial_rows(d_t, K), B] whose sum over
  * rows is the transform half's log|det|.  Replaces nets/resnet.py:105, coupling.py:147-159 and
- * :309-343 without materialising the [B, d_t * (3K-1)] logits.  hidden = 128, linear tails, K in {8, 16}. */
+ * :309-343 without materialising the [B, d_t * (3K-1)] logits.  hidden = 128, linear tails, K in {8, 10, 16}. */
 int vcnf_rqs_final_fused_supported(int32_t d_t, int32_t hidden, int32_t num_bins, int32_t tails);
 int64_t vcnf_rqs_final_fused_pack_floats(int32_t d_t, int32_t hidden, int32_t num_bins);
 int64_t vcnf_rqs_final_fused_partial_rows(int32_t d_t, int32_t num_bins);

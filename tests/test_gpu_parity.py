@@ -1433,7 +1433,8 @@ def test_permute_folded_into_fused_affine_layer(hip):
     (48, 8, 3, 16, 1000),        # d_id = d_t = 24: outside the one-kernel families
     (1024, 16, 2, 0, 300),       # config C5's layer shape
     (42, 8, 1, 0, 77),           # d_t = 21: last feature group partly empty
-    (10, 16, 2, 5, 4097)])
+    (10, 16, 2, 5, 4097),
+    (40, 10, 2, 0, 513)])        # the reference's default bin count (coupling.py:250-258)
 def test_final_layer_fused_with_splines(hip, d, k, blocks, ctx_dim, batch):
     """Conditioner trunk on PyTorch-ROCm, last Linear + splines in csrc/fused_final.hip (fp16 split-half
     matrix path, logits never materialised) against the three-step path and the oracle."""

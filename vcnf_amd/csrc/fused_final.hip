@@ -1,5 +1,5 @@
 // Last conditioner layer + splines of an RQS coupling in one kernel, for ANY number of
-// transformed features (hidden width 128, linear tails, 8 or 16 bins).
+// transformed features (hidden width 128, linear tails, 8, 10 (the reference's default) or 16 bins).
 //
 // The layer families of fused_layer*.hip run a whole coupling per launch.  Every other RQS
 // coupling used the three-step path, whose cost is the conditioner's last Linear: it writes
@@ -236,12 +236,12 @@ static int launch_final(const FinalArgs& a, int inverse, hipStream_t st) {
 }
 
 static bool final_shape_ok(int d_t, int hidden, int K, int tails) {
-  return d_t >= 1 && hidden == kFinH && (K == 8 || K == 16) && tails == VCNF_TAILS_LINEAR;
+  return d_t >= 1 && hidden == kFinH && (K == 8 || K == 10 || K == 16) && tails == VCNF_TAILS_LINEAR;
 }
 
-static int final_gw(int K) { return K == 8 ? FinalShape<8>::GW : FinalShape<16>::GW; }
-static int final_gfrag(int K) { return K == 8 ? FinalShape<8>::GFRAG : FinalShape<16>::GFRAG; }
-static int final_p4(int K) { return K == 8 ? FinalShape<8>::P4 : FinalShape<16>::P4; }
+static int final_gw(int K) { return K == 8 ? FinalShape<8>::GW : K == 10 ? FinalShape<10>::GW : FinalShape<16>::GW; }
+static int final_gfrag(int K) { return K == 8 ? FinalShape<8>::GFRAG : K == 10 ? FinalShape<10>::GFRAG : FinalShape<16>::GFRAG; }
+static int final_p4(int K) { return K == 8 ? FinalShape<8>::P4 : K == 10 ? FinalShape<10>::P4 : FinalShape<16>::P4; }
 
 }  // namespace vcnf
 
@@ -260,7 +260,7 @@ extern "C" int64_t vcnf_rqs_final_fused_pack_floats(int32_t d_t, int32_t hidden,
 
 /* rows of the partial log-det buffer [rows, batch] the kernel writes (one per group block) */
 extern "C" int64_t vcnf_rqs_final_fused_partial_rows(int32_t d_t, int32_t num_bins) {
-  if (num_bins != 8 && num_bins != 16) return 0;
+  if (num_bins != 8 && num_bins != 10 && num_bins != 16) return 0;
   const int ng = (d_t + 3) / 4, gw = final_gw(num_bins);
   return (ng + gw - 1) / gw;
 }
@@ -298,5 +298,5 @@ extern "C" int vcnf_rqs_final_fused_f32(const float* x, const float* h, float* y
   c.wh_scale = cfg->wh_scale;
   c.edge_logit = (float)log(exp(1.0 - (double)cfg->min_derivative) - 1.0);
   hipStream_t st = (hipStream_t)stream;
-  return K == 8 ? launch_final<8>(a, inverse, st) : launch_final<16>(a, inverse, st);
+  return K == 8 ? launch_final<8>(a, inverse, st) : K == 10 ? launch_final<10>(a, inverse, st) : launch_final<16>(a, inverse, st);
 }

@@ -1,5 +1,5 @@
 """Host side of csrc/fused_final.hip: the last conditioner layer + splines of an RQS coupling in one
-kernel for any number of transformed features (hidden width 128, linear tails, 8 or 16 bins).
+kernel for any number of transformed features (hidden width 128, linear tails, 8, 10 or 16 bins).
 
 Packed buffer (floats): for feature group g (features 4 g .. 4 g + 3), row block b, k-step s the two
 fragments hi | lo of 64 lanes x 8 halves, lane = 16 q' + i holding
