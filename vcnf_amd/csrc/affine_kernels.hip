@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void diag_gaussian_kernel(const GaussArgs a
 // Same arithmetic for D <= NC * G (a lane owns at most NC fixed columns): the per-column constants - and the exp()
 // of the scale - are computed once per lane instead of once per element (the loads from log_scale may alias the
 // outputs, so the compiler cannot hoist them out of the row loop above), and two rows are in flight per lane group.
-// 1M x 64: 201 -> us per call (HBM floor 32 us).
+// 1M x 64: 201 -> 151 us per call (HBM floor 32 us); the four-columns-per-lane kernel below takes the aligned shapes.
 template <int NC>
 __global__ __launch_bounds__(kBlock) void diag_gaussian_cols_kernel(const GaussArgs a) {
   const int g = threadIdx.x & (a.G - 1);
@@ -283,6 +283,57 @@ __global__ __launch_bounds__(kBlock) void diag_gaussian_cols_kernel(const GaussA
     }
     acc0 = group_sum(acc0, a.G);
     acc1 = group_sum(acc1, a.G);
+    if (g == 0) {
+      put_ld(a.logp, r, a.ld_sign * (a.norm - acc0), a.ld_mode);
+      if (two) put_ld(a.logp, r2, a.ld_sign * (a.norm - acc1), a.ld_mode);
+    }
+  }
+}
+
+// D % 4 == 0, D <= 256, 16-byte aligned rows: a lane owns FOUR ADJACENT columns (one 16-byte load / store per row), a
+// row is shared by G = pow2 >= D / 4 lanes, so the log2(G) shuffle steps of the row sum are paid once per four elements
+// (with one column per lane a 64-feature row spent more instructions in the reduction than in the density).
+__global__ __launch_bounds__(kBlock) void diag_gaussian_vec4_kernel(const GaussArgs a) {
+  const int g = threadIdx.x & (a.G - 1);
+  const int per_block = kBlock / a.G;
+  const bool have = 4 * g < a.D;
+  float ls[4], sc[4], lc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    ls[c] = have ? a.log_scale[4 * g + c] + a.log_temp : 0.f;
+    sc[c] = expf(ls[c]);
+    lc[c] = have ? a.loc[4 * g + c] : 0.f;
+  }
+  const long long step = (long long)gridDim.x * per_block;
+  const int d4 = a.D >> 2;
+  for (long long r = (long long)blockIdx.x * per_block + threadIdx.x / a.G; r < a.B; r += 2 * step) {
+    const long long r2 = r + step;
+    const bool two = r2 < a.B;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 p0 = have ? reinterpret_cast<const float4*>(a.in)[r * d4 + g] : z4;
+    const float4 p1 = (have && two) ? reinterpret_cast<const float4*>(a.in)[r2 * d4 + g] : z4;
+    const float v0[4] = {p0.x, p0.y, p0.z, p0.w}, v1[4] = {p1.x, p1.y, p1.z, p1.w};
+    float acc0 = 0.f, acc1 = 0.f;
+    float o0[4], o1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (a.sample) {
+        o0[c] = lc[c] + sc[c] * v0[c];
+        o1[c] = lc[c] + sc[c] * v1[c];
+        acc0 += ls[c] + 0.5f * v0[c] * v0[c];
+        acc1 += ls[c] + 0.5f * v1[c] * v1[c];
+      } else {
+        const float u0 = (v0[c] - lc[c]) / sc[c], u1 = (v1[c] - lc[c]) / sc[c];
+        acc0 += ls[c] + 0.5f * u0 * u0;
+        acc1 += ls[c] + 0.5f * u1 * u1;
+      }
+    }
+    if (a.sample && have) {
+      reinterpret_cast<float4*>(a.z)[r * d4 + g] = make_float4(o0[0], o0[1], o0[2], o0[3]);
+      if (two) reinterpret_cast<float4*>(a.z)[r2 * d4 + g] = make_float4(o1[0], o1[1], o1[2], o1[3]);
+    }
+    acc0 = group_sum(have ? acc0 : 0.f, a.G);
+    acc1 = group_sum(have ? acc1 : 0.f, a.G);
     if (g == 0) {
       put_ld(a.logp, r, a.ld_sign * (a.norm - acc0), a.ld_mode);
       if (two) put_ld(a.logp, r2, a.ld_sign * (a.norm - acc1), a.ld_mode);
@@ -385,9 +436,15 @@ static int gauss(const float* in, const float* loc, const float* log_scale, floa
   if (!in || !loc || !log_scale || !logp || (sample && !z)) return VCNF_ERR_NULL;
   GaussArgs a{in, loc, log_scale, z, logp, batch, features, pick_lanes(features), ld_mode, sample,
               log_temperature, ld_sign, (float)(-0.5 * (double)features * log(2.0 * M_PI))};
+  hipStream_t st = (hipStream_t)stream;
+  const bool al16 = ((reinterpret_cast<uintptr_t>(in) | (sample ? reinterpret_cast<uintptr_t>(z) : 0)) & 15) == 0;
+  if (features % 4 == 0 && features <= 256 && al16) {
+    a.G = pick_lanes(features / 4);
+    hipLaunchKernelGGL(diag_gaussian_vec4_kernel, grid_for(batch, a.G), dim3(kBlock), 0, st, a);
+    return launched();
+  }
   const int nc = (features + a.G - 1) / a.G;
   const dim3 grid = grid_for(batch, a.G);
-  hipStream_t st = (hipStream_t)stream;
   switch (nc) {
     case 1: hipLaunchKernelGGL(diag_gaussian_cols_kernel<1>, grid, dim3(kBlock), 0, st, a); break;
     case 2: hipLaunchKernelGGL(diag_gaussian_cols_kernel<2>, grid, dim3(kBlock), 0, st, a); break;
