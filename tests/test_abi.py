@@ -117,3 +117,49 @@ def test_validation_status_codes_of_the_later_entry_points():
                                          None, None, 0, 0, 1.0, None) == 2
     assert L.vcnf_affine_layer_fused_f32(fake, fake, fake, 4, 32, 0, 16, 16, 16, 64, 0.0, 9, fake, n,
                                          None, None, 0, 0, 1.0, None) in (2, 5)
+
+def test_validation_status_codes_of_the_round2_entry_points():
+    """Entry points added in round 2 (identity half, trunk, channel mix, 1x1 convolution, weight gradient, MAF map, affine
+    stack): shape / size / NULL validation on the host, nothing launched."""
+    L = vcnf_amd.lib()
+    cfg = _lib.make_cfg(16, "linear", tail_bound=3.0)
+    fake = ctypes.c_void_p(0x1000)
+    # identity half: bin counts / tails it is built for; d_id <= features; partial rows per 64 features
+    assert L.vcnf_rqs_identity_half_supported(16, _lib.TAILS_LINEAR) == 1 and L.vcnf_rqs_identity_half_supported(16, _lib.TAILS_CIRCULAR) == 0
+    assert L.vcnf_rqs_identity_half_supported(12, _lib.TAILS_LINEAR) == 0
+    assert L.vcnf_rqs_identity_half_partial_rows(512) == 8 and L.vcnf_rqs_identity_half_partial_rows(65) == 2
+    assert L.vcnf_rqs_identity_half_f32(fake, fake, fake, fake, 4, 8, fake, 9, fake, fake, fake, ctypes.byref(cfg), 0, 0, None, None) == 2
+    assert L.vcnf_rqs_identity_half_f32(fake, fake, fake, None, 4, 8, fake, 4, fake, fake, fake, ctypes.byref(cfg), 0, 0, None, None) == 1
+    assert L.vcnf_rqs_identity_half_f32(fake, fake, fake, fake, 0, 8, fake, 4, fake, fake, fake, ctypes.byref(cfg), 0, 0, None, None) == 0
+    # last-layer kernel: 8, 10 or 16 bins
+    assert [L.vcnf_rqs_final_fused_supported(512, 128, k, _lib.TAILS_LINEAR) for k in (8, 10, 12, 16)] == [1, 1, 0, 1]
+    # trunk: hidden 128, input width multiple of 16, 1-3 blocks; packed size
+    assert L.vcnf_resnet_trunk_supported(512, 128, 2) == 1 and L.vcnf_resnet_trunk_supported(500, 128, 2) == 0
+    assert L.vcnf_resnet_trunk_supported(512, 64, 2) == 0 and L.vcnf_resnet_trunk_supported(512, 128, 4) == 0
+    n = L.vcnf_resnet_trunk_pack_floats(512, 128, 2)
+    assert n == 8 * 32 * 256 + 128 + 2 * 2 * (64 * 256 + 128)
+    assert L.vcnf_resnet_trunk_f32(fake, fake, 4, 512, 128, 2, fake, n - 1, None) == 2
+    # channel mix: multiples of 4 up to 64
+    assert [L.vcnf_channel_mix_supported(c) for c in (4, 6, 48, 64, 68)] == [1, 0, 1, 1, 0]
+    assert L.vcnf_channel_mix_f32(fake, fake, fake, fake, 2, 6, 16, None) == 5
+    assert L.vcnf_channel_mix_f32(fake, fake, None, fake, 2, 8, 16, None) == 1
+    assert L.vcnf_channel_mix_f32(fake, fake, fake, fake, 0, 8, 16, None) == 0
+    # 1x1 convolution: c_in multiple of 16 up to 256; packed size must match
+    assert L.vcnf_conv1x1_supported(256, 256) == 1 and L.vcnf_conv1x1_supported(24, 256) == 0 and L.vcnf_conv1x1_supported(256, 257) == 0
+    m = L.vcnf_conv1x1_pack_floats(256, 256)
+    assert m == 8 * 16 * 2 * 64 * 4
+    assert L.vcnf_conv1x1_f16x3_f32(fake, fake, fake, m - 4, None, None, 2, 256, 256, 16, 1, 0.0, 1, 0.0, None, None) == 2
+    assert L.vcnf_conv1x1_f16x3_f32(fake, fake, fake, m, None, None, 0, 256, 256, 16, 1, 0.0, 1, 0.0, None, None) == 0
+    # weight gradient: slices and workspace size
+    assert L.vcnf_linear_wgrad_supported(128, 736) == 1 and L.vcnf_linear_wgrad_supported(100, 128) == 0
+    s = L.vcnf_linear_wgrad_slices(131072, 128, 128)
+    assert s == 512 and L.vcnf_linear_wgrad_slices(1000, 128, 128) == 4 and L.vcnf_linear_wgrad_slices(131072, 128, 736) == 86
+    assert L.vcnf_linear_wgrad_f32(fake, fake, fake, fake, fake, s * (128 * 128 + 128) - 1, 131072, 128, 128, 0, None) == 2
+    assert L.vcnf_linear_wgrad_f32(fake, fake, None, fake, fake, s * (128 * 128 + 128), 131072, 128, 128, 0, None) == 1
+    # MAF map: parameters must be 8-byte aligned
+    assert L.vcnf_maf_affine_f32(fake, ctypes.c_void_p(0x1004), fake, fake, 4, 7, 0, 0, 1.0, None) == 3
+    assert L.vcnf_maf_affine_f32(fake, fake, fake, None, 4, 7, 0, 0, 1.0, None) == 1
+    # affine stack: at most 16 layers
+    layers = (_lib.AffineStackLayer * 17)()
+    assert L.vcnf_affine_stack_fused_f32(fake, fake, fake, 4, 32, 17, ctypes.cast(layers, ctypes.c_void_p), -1, 16, 64, 0.0, 0,
+                                         fake, 100, None, 0, 0, 0, 1.0, None) in (2, 5)
