@@ -699,7 +699,7 @@ def conv1x1_fused(x, wpack, c_out, in_bias=None, out_bias=None, in_slope=None, o
     return out
 
 
-_WGRAD_WS = {}
+_WGRAD_WS = {}        # per-device workspace of the partial results; calls are ordered by the stream they run on
 
 
 def linear_wgrad(x, dy, want_bias=True):

@@ -277,6 +277,7 @@ class LinearFn(torch.autograd.Function):
         return F.linear(x, weight, bias)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gx = gw = gb = None
