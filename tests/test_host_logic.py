@@ -324,3 +324,21 @@ def test_refresh_packed_invalidates_every_cache():
     lay.prqct.__dict__['_fused_pack'] = (("key",), torch.zeros(3))
     model.load_state_dict(model.state_dict())
     assert lay.prqct.__dict__['_fused_pack'][0] is None
+    # caches added in round 2: trunk pack, affine stack buffer + descriptors, memoised stack plans, the GlowBlock's
+    # composed mixer, the conditioner's packed 1x1 convolution
+    lay.prqct.__dict__['_fused_trunk_pack'] = {'key': 3, 'buf': torch.zeros(2)}
+    blk.__dict__['_fused_affine_stack'] = {'key': 4, 'wpack': torch.zeros(2), 'desc': {True: ("k", 1)}}
+    model.__dict__['_stack_plans'] = {("k",): None}
+    glow = nf.flows.GlowBlock(8, 16)
+    keep = (torch.zeros(2), torch.zeros(2), torch.zeros(()))
+    glow.__dict__['_mix_cache'] = {True: {'key': 5, 'out': keep}, 'norm_ready': True}
+    glow.flows[0].flows[1].param_map.__dict__['_fused_conv_pack'] = {'key': 6, 'buf': torch.zeros(2)}
+    nf.refresh_packed(model)
+    nf.refresh_packed(glow)
+    assert lay.prqct.__dict__['_fused_trunk_pack']['key'] is None
+    assert blk.__dict__['_fused_affine_stack']['key'] is None and 'desc' not in blk.__dict__['_fused_affine_stack']
+    assert blk.__dict__['_fused_affine_stack']['wpack'] is not None           # buffers stay (rewritten in place later)
+    assert model.__dict__['_stack_plans'] == {}
+    assert glow.__dict__['_mix_cache'][True]['key'] is None and glow.__dict__['_mix_cache'][True]['out'] is keep
+    assert glow.__dict__['_mix_cache']['norm_ready'] is False
+    assert glow.flows[0].flows[1].param_map.__dict__['_fused_conv_pack']['key'] is None
