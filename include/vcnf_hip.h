@@ -244,6 +244,19 @@ int vcnf_linear_wgrad_f32(const float* x, const float* dy, float* dw, float* db,
                           int64_t workspace_floats, int64_t batch, int32_t in_features, int32_t out_features,
                           int accumulate, void* stream);
 
+/* First two layers of the Glow conditioner in one launch (nets/cnn.py:20-52): y = act2(W2 act1(conv3x3(x; W1, padding 1)
+ * + b1) + b2) with x [batch, c_in, height, width], 256 hidden and 256 output channels, act = LeakyReLU(slope); the
+ * hidden activation between the two layers stays on chip.  Matrix path and saturation counter as
+ * vcnf_conv1x1_f16x3_f32.  w1pack: the [256, 9 c_in] patch matrix (k = ci * 9 + ky * 3 + kx, zero padded to a multiple of
+ * 16) as A fragments, vcnf_conv3x3_1x1_pack_floats(c_in) floats; w2pack: vcnf_conv1x1_pack_floats(256, 256) floats
+ * (vcnf_amd/nets/cnn.py::pack_conv1x1).  c_in <= 24. */
+int vcnf_conv3x3_1x1_supported(int32_t c_in, int32_t hidden, int32_t c_out);
+int64_t vcnf_conv3x3_1x1_pack_floats(int32_t c_in);
+int vcnf_conv3x3_1x1_f16x3_f32(const float* x, float* y, const float* w1pack, int64_t w1pack_floats,
+                               const float* w2pack, int64_t w2pack_floats, const float* b1, const float* b2,
+                               int64_t batch, int32_t c_in, int32_t height, int32_t width, float slope1, float slope2,
+                               int32_t* sat_count, void* stream);
+
 /* Identity half of one RQS coupling layer in one launch (coupling.py:76-116): for f < d_id and v = x[b, identity_idx[f]]
  *   y = S_f(v) (inverse = 0) or S_f^-1(v) (inverse = 1) with the batch-shared unconditional spline of feature f
  *       (PiecewiseRationalQuadraticCDF, coupling.py:165-246), or y = v when shared_w/h/d are all NULL;

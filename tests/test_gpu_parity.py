@@ -914,6 +914,35 @@ def test_conv1x1_fused_kernel(hip, c_in, c_out, h, w):
     assert nf.check_saturation() == 0
 
 
+@pytest.mark.parametrize("c_in,h,w", [(6, 16, 16), (12, 8, 8), (24, 4, 4), (3, 5, 7), (1, 2, 2)])
+def test_conv3x3_1x1_fused_kernel(hip, c_in, h, w):
+    """csrc/conv3x3_1x1.hip: y = leaky(W2 leaky(conv3x3(x, padding 1) + b1) + b2) in one launch (first two layers of the
+    Glow conditioner, nets/cnn.py:20-52) on the fp16 split-half matrix path, against fp64 beside torch's own fp32
+    composition; image borders (zero padding), passes crossing image boundaries, ragged batches."""
+    import torch.nn.functional as F
+    from vcnf_amd.nets.cnn import pack_conv1x1
+    g = torch.Generator().manual_seed(31 * c_in + h)
+    w1 = (torch.randn(256, c_in, 3, 3, generator=g) / (3.0 * c_in ** 0.5)).cuda()
+    w2 = (torch.randn(256, 256, generator=g) / 16).cuda()
+    b1, b2 = torch.randn(256, generator=g).cuda(), torch.randn(256, generator=g).cuda()
+    k1 = 9 * c_in
+    p1 = pack_conv1x1(F.pad(w1.reshape(256, k1), (0, (-k1) % 16)))
+    p2 = pack_conv1x1(w2)
+    assert p1.numel() == int(_lib.lib().vcnf_conv3x3_1x1_pack_floats(c_in))
+    for b in (1, 5, 67):
+        x = torch.randn(b, c_in, h, w, generator=g).cuda()
+        got = _lib.conv3x3_1x1_fused(x, p1, p2, b1, b2, 0.1, 0.0)
+
+        def ref(dt):
+            t = F.leaky_relu(F.conv2d(x.to(dt), w1.to(dt), b1.to(dt), padding=1), 0.1)
+            return F.leaky_relu(torch.einsum("oc,bchw->bohw", w2.to(dt), t) + b2.to(dt).view(1, -1, 1, 1), 0.0)
+        r64, r32 = ref(torch.float64), ref(torch.float32)
+        scale = float(r64.abs().max())
+        e_got, e_ref = float((got.double() - r64).abs().max()), float((r32.double() - r64).abs().max())
+        assert got.shape == r64.shape and e_got <= 2.0 * e_ref + 2e-6 * scale, (c_in, b, e_got, e_ref)
+    assert nf.check_saturation() == 0
+
+
 def test_convnet2d_fused_middle_layer(hip):
     """ConvNet2d (Glow conditioner, nets/cnn.py:20-52) with its 1x1 convolution, both LeakyReLUs and two bias adds on
     csrc/conv1x1.hip against the same module evaluated layer by layer, and the .data / refresh_packed contract."""

@@ -64,6 +64,9 @@ PROTOTYPES = {
     "vcnf_linear_wgrad_supported": ([_I32, _I32], _INT),
     "vcnf_linear_wgrad_slices": ([_I64, _I32, _I32], _I64),
     "vcnf_linear_wgrad_f32": ([_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _INT, _P], _INT),
+    "vcnf_conv3x3_1x1_supported": ([_I32, _I32, _I32], _INT),
+    "vcnf_conv3x3_1x1_pack_floats": ([_I32], _I64),
+    "vcnf_conv3x3_1x1_f16x3_f32": ([_P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _F32, _F32, _P, _P], _INT),
     "vcnf_channel_mix_supported": ([_I32], _INT),
     "vcnf_channel_mix_f32": ([_P, _P, _P, _P, _I64, _I32, _I64, _P], _INT),
     "vcnf_rqs_identity_half_supported": ([_I32, _I32], _INT),
@@ -270,7 +273,7 @@ def check_saturation(device="cuda", model=None):
         for m in model.modules():
             if hasattr(m, "fused_precision"):
                 m.fused_precision = "fp32"
-            if hasattr(m, "fused_conv1x1"):           # ConvNet2d: back to the library's fp32 1x1 convolution
+            if hasattr(m, "fused_conv1x1"):           # ConvNet2d: back to the library's fp32 convolutions
                 m.fused_conv1x1 = False
     return n
 
@@ -725,6 +728,21 @@ def linear_wgrad(x, dy, want_bias=True):
                                          int(n_out), 0, _stream())
     _check(st, "vcnf_linear_wgrad_f32")
     return dw, db
+
+
+def conv3x3_1x1_fused(x, w1pack, w2pack, b1, b2, slope1, slope2):
+    """leaky(W2 leaky(conv3x3(x) + b1) + b2) for NCHW x with 256 hidden / output channels in one launch
+    (csrc/conv3x3_1x1.hip); the hidden activation between the layers never reaches memory."""
+    dev = require_device(x, w1pack, w2pack, b1, b2)
+    x = x.contiguous()
+    b, c_in, h, w = x.shape
+    out = torch.empty((b, 256, h, w), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("conv3x3_1x1_fused"):
+        st = lib().vcnf_conv3x3_1x1_f16x3_f32(_ptr(x), _ptr(out), _ptr(w1pack), w1pack.numel(), _ptr(w2pack), w2pack.numel(),
+                                              _ptr(b1), _ptr(b2), b, int(c_in), int(h), int(w), float(slope1), float(slope2),
+                                              _ptr(saturation_counter(dev)), _stream())
+    _check(st, "vcnf_conv3x3_1x1_f16x3_f32")
+    return out
 
 
 def channel_mix(z, matrix, shift):

@@ -64,7 +64,42 @@ class ConvNet2d(nn.Module):
             cache['key'] = key
         return cache['buf']
 
+    def _packed_conv3x3(self):
+        c1 = self.net[0]
+        key = (c1.weight.data_ptr(), c1.weight._version, str(c1.weight.device))
+        cache = self.__dict__.setdefault('_fused_conv3_pack', {})
+        if cache.get('key') != key:
+            with torch.no_grad():
+                k1 = c1.in_channels * 9
+                w = c1.weight.detach().reshape(c1.out_channels, k1)          # k = ci * 9 + ky * 3 + kx
+                w = F.pad(w, (0, (-k1) % 16))
+                buf = pack_conv1x1(w)
+            old = cache.get('buf')
+            if old is not None and old.shape == buf.shape and old.device == buf.device:
+                old.copy_(buf)
+            else:
+                cache['buf'] = buf
+            cache['key'] = key
+        return cache['buf']
+
+    def _first_two_fusable(self):
+        """3x3 convolution (padding 1, stride 1) into 256 channels followed by the 256 -> 256 1x1 convolution: both on
+        csrc/conv3x3_1x1.hip, the hidden activation between them stays on chip."""
+        from .. import _lib
+        c1, c2 = self.net[0], self.net[2]
+        return (self.fused_conv3x3 and c1.kernel_size == (3, 3) and c1.padding == (1, 1) and c1.stride == (1, 1)
+                and c1.dilation == (1, 1) and c1.groups == 1 and c1.padding_mode == 'zeros'
+                and bool(_lib.lib().vcnf_conv3x3_1x1_supported(c1.in_channels, c1.out_channels, c2.out_channels)))
+
+    fused_conv3x3 = True
+
     def forward(self, x):
+        if self._fusable(x) and self._first_two_fusable():
+            from .. import _lib
+            c1, a1, c2, a2, c3 = self.net
+            h = _lib.conv3x3_1x1_fused(x, self._packed_conv3x3(), self._packed_conv1x1(), c1.bias, c2.bias,
+                                       float(a1.negative_slope), float(a2.negative_slope))
+            return c3(h)
         if self._fusable(x):
             from .. import _lib
             c1, a1, c2, a2, c3 = self.net
