@@ -64,6 +64,7 @@ __global__ __launch_bounds__(kC31Block, 2) void conv3x3_1x1_f16x3_kernel(const C
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     __syncthreads();                       // the previous pass's fragments (both layers) are consumed
     // ---- (1) patches of the pass's 64 pixels -> B fragments of the first layer: task = (pixel, 8 consecutive k)
+#pragma unroll 1
     for (int id = tid; id < kC31Pix * 2 * KS1; id += kC31Block) {
       const int pxl = id & 63, kg8 = id >> 6;
       const long long g = tile * kC31Pix + pxl;
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(kC31Block, 2) void conv3x3_1x1_f16x3_kernel(const C
       bf1[((ks * 2 + ct) * 2 + 1) * 64 + ln] = __builtin_bit_cast(uint4, lo);
     }
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     // ---- (2) first layer for this wave's 32 hidden channels, result -> B fragments of the second layer
 #pragma unroll 1
     for (int ct = 0; ct < 2; ++ct) {
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(kC31Block, 2) void conv3x3_1x1_f16x3_kernel(const C
       }
     }
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     // ---- (3) + (4) second layer (1x1) and stores
 #pragma unroll 1
     for (int ct = 0; ct < 2; ++ct) {
