@@ -150,6 +150,14 @@ def test_validation_status_codes_of_the_round2_entry_points():
     assert m == 8 * 16 * 2 * 64 * 4
     assert L.vcnf_conv1x1_f16x3_f32(fake, fake, fake, m - 4, None, None, 2, 256, 256, 16, 1, 0.0, 1, 0.0, None, None) == 2
     assert L.vcnf_conv1x1_f16x3_f32(fake, fake, fake, m, None, None, 0, 256, 256, 16, 1, 0.0, 1, 0.0, None, None) == 0
+    # first two conditioner layers in one launch: c_in <= 24, 256 hidden / output channels, packed sizes
+    assert L.vcnf_conv3x3_1x1_supported(6, 256, 256) == 1 and L.vcnf_conv3x3_1x1_supported(25, 256, 256) == 0
+    assert L.vcnf_conv3x3_1x1_supported(6, 128, 256) == 0
+    assert L.vcnf_conv3x3_1x1_pack_floats(6) == 8 * 4 * 2 * 64 * 4 and L.vcnf_conv3x3_1x1_pack_floats(24) == 8 * 14 * 2 * 64 * 4
+    assert L.vcnf_conv3x3_1x1_f16x3_f32(fake, fake, fake, 8 * 4 * 2 * 64 * 4, fake, m - 4, None, None, 2, 6, 16, 16, 0.0, 0.0,
+                                        None, None) == 2
+    assert L.vcnf_conv3x3_1x1_f16x3_f32(fake, fake, fake, 8 * 4 * 2 * 64 * 4, fake, m, None, None, 0, 6, 16, 16, 0.0, 0.0,
+                                        None, None) == 0
     # weight gradient: slices and workspace size
     assert L.vcnf_linear_wgrad_supported(128, 736) == 1 and L.vcnf_linear_wgrad_supported(100, 128) == 0
     s = L.vcnf_linear_wgrad_slices(131072, 128, 128)
