@@ -257,6 +257,25 @@ int vcnf_conv3x3_1x1_f16x3_f32(const float* x, float* y, const float* w1pack, in
                                int64_t batch, int32_t c_in, int32_t height, int32_t width, float slope1, float slope2,
                                int32_t* sat_count, void* stream);
 
+/* The whole Glow conditioner Conv3x3(c_in -> 256), LeakyReLU, Conv1x1(256 -> 256), LeakyReLU, Conv3x3(256 -> c_out)
+ * (nets/cnn.py:20-52, flows/affine/glow.py:37-47) in two launches, neither 256-channel activation ever in memory:
+ *   vcnf_convnet3_taps_f16x3_f32: the first two layers as vcnf_conv3x3_1x1_f16x3_f32, then the last layer's nine taps as
+ *       1x1 convolutions  z[b, t * c_out + o, p] = sum_c W3[o, c, tap t] y[b, c, p],  t = ky * 3 + kx  (no shift);
+ *       w3pack: the tap matrix [9 c_out, 256] as A fragments, vcnf_convnet3_w3_pack_floats(c_out) floats
+ *       (vcnf_amd/nets/cnn.py::pack_conv1x1 with ceil(9 c_out / 32) row blocks);
+ *   vcnf_col2im3x3_f32: out[b, o, py, px] = bias[o] + sum over the taps inside the image of
+ *       z[b, t * channels + o, py + dy - 1, px + dx - 1]  (the convolution's zero padding).
+ * c_in <= 24, c_out <= 56.  Matrix path and saturation counter as vcnf_conv1x1_f16x3_f32. */
+int vcnf_convnet3_supported(int32_t c_in, int32_t hidden, int32_t c_out);
+int64_t vcnf_convnet3_w3_pack_floats(int32_t c_out);
+int vcnf_convnet3_taps_f16x3_f32(const float* x, float* z, const float* w1pack, int64_t w1pack_floats,
+                                 const float* w2pack, int64_t w2pack_floats, const float* w3pack, int64_t w3pack_floats,
+                                 const float* b1, const float* b2, int64_t batch, int32_t c_in, int32_t c_out,
+                                 int32_t height, int32_t width, float slope1, float slope2, int32_t* sat_count,
+                                 void* stream);
+int vcnf_col2im3x3_f32(const float* z, const float* bias, float* out, int64_t batch, int32_t channels,
+                       int32_t height, int32_t width, void* stream);
+
 /* Identity half of one RQS coupling layer in one launch (coupling.py:76-116): for f < d_id and v = x[b, identity_idx[f]]
  *   y = S_f(v) (inverse = 0) or S_f^-1(v) (inverse = 1) with the batch-shared unconditional spline of feature f
  *       (PiecewiseRationalQuadraticCDF, coupling.py:165-246), or y = v when shared_w/h/d are all NULL;

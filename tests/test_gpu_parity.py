@@ -943,6 +943,38 @@ def test_conv3x3_1x1_fused_kernel(hip, c_in, h, w):
     assert nf.check_saturation() == 0
 
 
+@pytest.mark.parametrize("c_in,c_out,h,w", [(6, 12, 16, 16), (12, 24, 8, 8), (24, 48, 4, 4), (3, 5, 5, 7), (2, 56, 3, 3)])
+def test_convnet3_fused_taps_and_col2im(hip, c_in, c_out, h, w):
+    """Whole Glow conditioner (Conv3x3, LeakyReLU, Conv1x1, LeakyReLU, Conv3x3; nets/cnn.py:20-52) in two launches
+    (csrc/conv3x3_1x1.hip: fused kernel up to the last layer's nine tap results, then col2im) against fp64 beside torch's
+    own fp32 composition; borders, passes crossing images, ragged batches, partial row blocks of the tap matrix."""
+    import torch.nn.functional as F
+    from vcnf_amd.nets.cnn import pack_conv1x1
+    g = torch.Generator().manual_seed(17 * c_in + c_out)
+    w1 = (torch.randn(256, c_in, 3, 3, generator=g) / (3.0 * c_in ** 0.5)).cuda()
+    w2 = (torch.randn(256, 256, generator=g) / 16).cuda()
+    w3 = (torch.randn(c_out, 256, 3, 3, generator=g) / 48).cuda()
+    b1, b2, b3 = (torch.randn(n, generator=g).cuda() for n in (256, 256, c_out))
+    k1 = 9 * c_in
+    p1 = pack_conv1x1(F.pad(w1.reshape(256, k1), (0, (-k1) % 16)))
+    p2 = pack_conv1x1(w2)
+    p3 = pack_conv1x1(w3.permute(2, 3, 0, 1).reshape(9 * c_out, 256), row_blocks=(9 * c_out + 31) // 32)
+    assert p3.numel() == int(_lib.lib().vcnf_convnet3_w3_pack_floats(c_out))
+    for b in (1, 5, 67):
+        x = torch.randn(b, c_in, h, w, generator=g).cuda()
+        got = _lib.convnet3_fused(x, p1, p2, p3, b1, b2, b3, c_out, 0.1, 0.0)
+
+        def ref(dt):
+            t = F.leaky_relu(F.conv2d(x.to(dt), w1.to(dt), b1.to(dt), padding=1), 0.1)
+            t = F.leaky_relu(F.conv2d(t, w2.to(dt).view(256, 256, 1, 1), b2.to(dt)), 0.0)
+            return F.conv2d(t, w3.to(dt), b3.to(dt), padding=1)
+        r64, r32 = ref(torch.float64), ref(torch.float32)
+        scale = float(r64.abs().max())
+        e_got, e_ref = float((got.double() - r64).abs().max()), float((r32.double() - r64).abs().max())
+        assert got.shape == r64.shape and e_got <= 2.0 * e_ref + 2e-6 * scale, (c_in, c_out, b, e_got, e_ref)
+    assert nf.check_saturation() == 0
+
+
 def test_convnet2d_fused_middle_layer(hip):
     """ConvNet2d (Glow conditioner, nets/cnn.py:20-52) with its 1x1 convolution, both LeakyReLUs and two bias adds on
     csrc/conv1x1.hip against the same module evaluated layer by layer, and the .data / refresh_packed contract."""

@@ -67,6 +67,11 @@ PROTOTYPES = {
     "vcnf_conv3x3_1x1_supported": ([_I32, _I32, _I32], _INT),
     "vcnf_conv3x3_1x1_pack_floats": ([_I32], _I64),
     "vcnf_conv3x3_1x1_f16x3_f32": ([_P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _F32, _F32, _P, _P], _INT),
+    "vcnf_convnet3_supported": ([_I32, _I32, _I32], _INT),
+    "vcnf_convnet3_w3_pack_floats": ([_I32], _I64),
+    "vcnf_convnet3_taps_f16x3_f32": ([_P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _F32, _F32,
+                                      _P, _P], _INT),
+    "vcnf_col2im3x3_f32": ([_P, _P, _P, _I64, _I32, _I32, _I32, _P], _INT),
     "vcnf_channel_mix_supported": ([_I32], _INT),
     "vcnf_channel_mix_f32": ([_P, _P, _P, _P, _I64, _I32, _I64, _P], _INT),
     "vcnf_rqs_identity_half_supported": ([_I32, _I32], _INT),
@@ -742,6 +747,25 @@ def conv3x3_1x1_fused(x, w1pack, w2pack, b1, b2, slope1, slope2):
                                               _ptr(b1), _ptr(b2), b, int(c_in), int(h), int(w), float(slope1), float(slope2),
                                               _ptr(saturation_counter(dev)), _stream())
     _check(st, "vcnf_conv3x3_1x1_f16x3_f32")
+    return out
+
+
+def convnet3_fused(x, w1pack, w2pack, w3pack, b1, b2, b3, c_out, slope1, slope2):
+    """Conv3x3 -> LeakyReLU -> Conv1x1 -> LeakyReLU -> Conv3x3 of the Glow conditioner (256 hidden channels) in two launches
+    (csrc/conv3x3_1x1.hip): the fused kernel up to the last layer's nine tap results, then their shift-and-add."""
+    dev = require_device(x, w1pack, w2pack, w3pack, b1, b2, b3)
+    x = x.contiguous()
+    b, c_in, h, w = x.shape
+    z = torch.empty((b, 9 * c_out, h, w), dtype=torch.float32, device=dev)
+    out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("convnet3_fused"):
+        st = lib().vcnf_convnet3_taps_f16x3_f32(_ptr(x), _ptr(z), _ptr(w1pack), w1pack.numel(), _ptr(w2pack), w2pack.numel(),
+                                                _ptr(w3pack), w3pack.numel(), _ptr(b1), _ptr(b2), b, int(c_in), int(c_out),
+                                                int(h), int(w), float(slope1), float(slope2),
+                                                _ptr(saturation_counter(dev)), _stream())
+        _check(st, "vcnf_convnet3_taps_f16x3_f32")
+        st = lib().vcnf_col2im3x3_f32(_ptr(z), _ptr(b3), _ptr(out), b, int(c_out), int(h), int(w), _stream())
+    _check(st, "vcnf_col2im3x3_f32")
     return out
 
 

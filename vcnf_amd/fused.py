@@ -257,7 +257,7 @@ def refresh_packed(module):
         if d.get('_fused_pack') is not None:
             d['_fused_pack'] = (None, d['_fused_pack'][1])
         for name in ('_fused_affine_pack', '_fused_affine_stack', '_fused_final_pack', '_fused_trunk_pack', '_fused_conv_pack',
-                     '_fused_conv3_pack'):
+                     '_fused_conv3_pack', '_fused_taps_pack'):
             if isinstance(d.get(name), dict):
                 d[name]['key'] = None
                 d[name].pop('desc', None)                   # stack launch descriptors (permutation rows)

@@ -93,7 +93,40 @@ class ConvNet2d(nn.Module):
 
     fused_conv3x3 = True
 
+    def _packed_taps(self):
+        c3 = self.net[4]
+        key = (c3.weight.data_ptr(), c3.weight._version, str(c3.weight.device))
+        cache = self.__dict__.setdefault('_fused_taps_pack', {})
+        if cache.get('key') != key:
+            with torch.no_grad():
+                co = c3.out_channels
+                w = c3.weight.detach().permute(2, 3, 0, 1).reshape(9 * co, c3.in_channels)     # row t * c_out + o
+                buf = pack_conv1x1(w, row_blocks=(9 * co + 31) // 32)
+            old = cache.get('buf')
+            if old is not None and old.shape == buf.shape and old.device == buf.device:
+                old.copy_(buf)
+            else:
+                cache['buf'] = buf
+            cache['key'] = key
+        return cache['buf']
+
+    def _all_three_fusable(self):
+        """... followed by a 3x3 convolution (padding 1) to at most 56 channels: its nine taps run as one more matrix
+        phase of the same kernel, a second small kernel shifts and adds them (csrc/conv3x3_1x1.hip)."""
+        from .. import _lib
+        c1, c3 = self.net[0], self.net[4]
+        return (self.fused_conv_taps and c3.kernel_size == (3, 3) and c3.padding == (1, 1) and c3.stride == (1, 1)
+                and c3.dilation == (1, 1) and c3.groups == 1 and c3.padding_mode == 'zeros' and c3.in_channels == 256
+                and bool(_lib.lib().vcnf_convnet3_supported(c1.in_channels, 256, c3.out_channels)))
+
+    fused_conv_taps = True
+
     def forward(self, x):
+        if self._fusable(x) and self._first_two_fusable() and self._all_three_fusable():
+            from .. import _lib
+            c1, a1, c2, a2, c3 = self.net
+            return _lib.convnet3_fused(x, self._packed_conv3x3(), self._packed_conv1x1(), self._packed_taps(), c1.bias,
+                                       c2.bias, c3.bias, c3.out_channels, float(a1.negative_slope), float(a2.negative_slope))
         if self._fusable(x) and self._first_two_fusable():
             from .. import _lib
             c1, a1, c2, a2, c3 = self.net
@@ -110,21 +143,21 @@ class ConvNet2d(nn.Module):
         return self.net(x)
 
 
-def pack_conv1x1(w):
+def pack_conv1x1(w, row_blocks=8):
     """W [c_out, c_in] -> A fragments of v_mfma_f32_32x32x16_f16 for csrc/conv1x1.hip: [8 row blocks][c_in / 16]
-    [hi | lo][64 lanes][8 halves], lane l holding row 32 rb + l % 32, input channels 16 ks + 8 (l / 32) + i; rows beyond
-    c_out are zero; hi / lo = the fp16 split of fused._split_halves (w ~ hi + lo / 2048)."""
+    [hi | lo][64 lanes][8 halves] (``row_blocks`` blocks of 32 rows), lane l holding row 32 rb + l % 32, input channels
+    16 ks + 8 (l / 32) + i; rows beyond c_out are zero; hi / lo = the fp16 split of fused._split_halves (w ~ hi + lo / 2048)."""
     from ..fused import _split_halves, _as_floats
     c_out, c_in = w.shape
     dev = w.device
-    rb = torch.arange(8, device=dev).view(-1, 1, 1, 1)
+    rb = torch.arange(row_blocks, device=dev).view(-1, 1, 1, 1)
     ks = torch.arange(c_in // 16, device=dev).view(1, -1, 1, 1)
     lane = torch.arange(64, device=dev).view(1, 1, -1, 1)
     i = torch.arange(8, device=dev).view(1, 1, 1, -1)
-    shape = (8, c_in // 16, 64, 8)
+    shape = (row_blocks, c_in // 16, 64, 8)
     rows = (32 * rb + (lane & 31)).expand(shape)
     cols = (16 * ks + 8 * (lane >> 5) + i).expand(shape)
     ok = rows < c_out
     vals = torch.where(ok, w[torch.where(ok, rows, torch.zeros_like(rows)), cols], torch.zeros((), device=dev, dtype=w.dtype))
-    hi, lo = _split_halves(vals)                                   # [8, ks, 64, 8]
-    return _as_floats(torch.stack([hi, lo], dim=2)).contiguous()   # [8, ks, 2, 64, 8]
+    hi, lo = _split_halves(vals)                                   # [row blocks, ks, 64, 8]
+    return _as_floats(torch.stack([hi, lo], dim=2)).contiguous()   # [row blocks, ks, 2, 64, 8]
