@@ -158,6 +158,12 @@ def test_validation_status_codes_of_the_round2_entry_points():
                                         None, None) == 2
     assert L.vcnf_conv3x3_1x1_f16x3_f32(fake, fake, fake, 8 * 4 * 2 * 64 * 4, fake, m, None, None, 0, 6, 16, 16, 0.0, 0.0,
                                         None, None) == 0
+    # whole conditioner: tap matrix of the last layer, col2im
+    assert L.vcnf_convnet3_supported(6, 256, 12) == 1 and L.vcnf_convnet3_supported(6, 256, 57) == 0
+    assert L.vcnf_convnet3_w3_pack_floats(12) == 4 * 16 * 2 * 64 * 4 and L.vcnf_convnet3_w3_pack_floats(48) == 14 * 16 * 2 * 64 * 4
+    assert L.vcnf_convnet3_taps_f16x3_f32(fake, fake, fake, 8 * 4 * 2 * 64 * 4, fake, m, fake, 8, None, None, 2, 6, 12, 16, 16,
+                                          0.0, 0.0, None, None) == 2
+    assert L.vcnf_col2im3x3_f32(fake, None, fake, 0, 12, 16, 16, None) == 0 and L.vcnf_col2im3x3_f32(None, None, fake, 2, 12, 16, 16, None) == 1
     # weight gradient: slices and workspace size
     assert L.vcnf_linear_wgrad_supported(128, 736) == 1 and L.vcnf_linear_wgrad_supported(100, 128) == 0
     s = L.vcnf_linear_wgrad_slices(131072, 128, 128)
