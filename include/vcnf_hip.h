@@ -276,6 +276,15 @@ int vcnf_convnet3_taps_f16x3_f32(const float* x, float* z, const float* w1pack, 
 int vcnf_col2im3x3_f32(const float* z, const float* bias, float* out, int64_t batch, int32_t channels,
                        int32_t height, int32_t width, void* stream);
 
+/* Fused elementwise maps of a residual block of the conditioner and of its backward (training path;
+ * nets/resnet.py:38-57 under autograd), n contiguous floats each:
+ *   op 0: out0 = a + b * sigmoid(c)                          (block output: input + second Linear gated by the context)
+ *   op 1: out0 = a * s, out1 = a * b * s * (1 - s), s = sigmoid(c)     (gradients of the gated product)
+ *   op 2: out0 = a where b > 0, else 0                       (ReLU backward, b = the ReLU's output; c unused)
+ *   op 3: out0 = c + (a where b > 0, else 0)                 (ReLU backward joined with the skip connection's gradient) */
+int vcnf_resblock_elementwise_f32(int op, const float* a, const float* b, const float* c, float* out0, float* out1,
+                                  int64_t n, void* stream);
+
 /* Identity half of one RQS coupling layer in one launch (coupling.py:76-116): for f < d_id and v = x[b, identity_idx[f]]
  *   y = S_f(v) (inverse = 0) or S_f^-1(v) (inverse = 1) with the batch-shared unconditional spline of feature f
  *       (PiecewiseRationalQuadraticCDF, coupling.py:165-246), or y = v when shared_w/h/d are all NULL;

@@ -170,6 +170,10 @@ def test_validation_status_codes_of_the_round2_entry_points():
     assert s == 512 and L.vcnf_linear_wgrad_slices(1000, 128, 128) == 4 and L.vcnf_linear_wgrad_slices(131072, 128, 736) == 86
     assert L.vcnf_linear_wgrad_f32(fake, fake, fake, fake, fake, s * (128 * 128 + 128) - 1, 131072, 128, 128, 0, None) == 2
     assert L.vcnf_linear_wgrad_f32(fake, fake, None, fake, fake, s * (128 * 128 + 128), 131072, 128, 128, 0, None) == 1
+    # residual-block maps: op 0-3, op 1 needs the second output
+    assert L.vcnf_resblock_elementwise_f32(4, fake, fake, fake, fake, None, 8, None) == 5
+    assert L.vcnf_resblock_elementwise_f32(1, fake, fake, fake, fake, None, 8, None) == 1
+    assert L.vcnf_resblock_elementwise_f32(2, fake, fake, None, fake, None, 0, None) == 0
     # MAF map: parameters must be 8-byte aligned
     assert L.vcnf_maf_affine_f32(fake, ctypes.c_void_p(0x1004), fake, fake, 4, 7, 0, 0, 1.0, None) == 3
     assert L.vcnf_maf_affine_f32(fake, fake, fake, None, 4, 7, 0, 0, 1.0, None) == 1

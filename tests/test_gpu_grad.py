@@ -397,14 +397,17 @@ def test_linear_wgrad_kernel(hip, n_in, n_out, b):
     assert none is None and torch.equal(dw2, dw)                     # deterministic
 
 
-def test_resnet_training_uses_wgrad_kernel_and_matches_autograd(hip):
+@pytest.mark.parametrize("ctx_dim", [16, None])
+def test_resnet_training_uses_wgrad_kernel_and_matches_autograd(hip, ctx_dim):
     """ResidualNet at a training batch size: the dense layers' weight / bias gradients come from the weight-gradient
-    kernel (vcnf_amd/autograd.py::LinearFn) and equal PyTorch's own autograd of the same network to rounding."""
+    kernel (vcnf_amd/autograd.py::LinearFn), every residual block is one autograd node with fused elementwise maps
+    (ResBlockFn, csrc/resblock_ops.hip; with and without the context gate), and all gradients equal PyTorch's own
+    autograd of the same network to rounding."""
     from vcnf_amd import _lib, autograd
     torch.manual_seed(3)
-    net = nf.nets.ResidualNet(48, 96, 128, context_features=16, num_blocks=2).cuda()
-    x = torch.randn(8192 + 5, 48, device="cuda")
-    ctx = torch.randn(8192 + 5, 16, device="cuda")
+    net = nf.nets.ResidualNet(48 if ctx_dim else 64, 96, 128, context_features=ctx_dim, num_blocks=2).cuda()
+    x = torch.randn(8192 + 5, 48 if ctx_dim else 64, device="cuda")
+    ctx = torch.randn(8192 + 5, 16, device="cuda") if ctx_dim else None
     up = torch.randn(8192 + 5, 96, device="cuda")
 
     def grads(min_batch):
@@ -422,7 +425,7 @@ def test_resnet_training_uses_wgrad_kernel_and_matches_autograd(hip):
             autograd.WGRAD_MIN_BATCH = old
     mine, launches = grads(8192)
     ref, none = grads(1 << 40)
-    assert launches == 1 + 2 * 2 + 2 + 1 and none == 0                # initial, 2 x 2 block layers, 2 context layers, final
+    assert launches == 1 + 2 * 2 + (2 if ctx_dim else 0) + 1 and none == 0     # initial, 2 x 2 block layers, context layers, final
     for a, b in zip(mine, ref):
         assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-6
 

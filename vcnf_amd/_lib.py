@@ -72,6 +72,7 @@ PROTOTYPES = {
     "vcnf_convnet3_taps_f16x3_f32": ([_P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _F32, _F32,
                                       _P, _P], _INT),
     "vcnf_col2im3x3_f32": ([_P, _P, _P, _I64, _I32, _I32, _I32, _P], _INT),
+    "vcnf_resblock_elementwise_f32": ([_INT, _P, _P, _P, _P, _P, _I64, _P], _INT),
     "vcnf_channel_mix_supported": ([_I32], _INT),
     "vcnf_channel_mix_f32": ([_P, _P, _P, _P, _I64, _I32, _I64, _P], _INT),
     "vcnf_rqs_identity_half_supported": ([_I32, _I32], _INT),
@@ -767,6 +768,20 @@ def convnet3_fused(x, w1pack, w2pack, w3pack, b1, b2, b3, c_out, slope1, slope2)
         st = lib().vcnf_col2im3x3_f32(_ptr(z), _ptr(b3), _ptr(out), b, int(c_out), int(h), int(w), _stream())
     _check(st, "vcnf_col2im3x3_f32")
     return out
+
+
+def resblock_op(op, a, b, c=None, two_outputs=False):
+    """Fused elementwise map of csrc/resblock_ops.hip on contiguous fp32 tensors of one shape (ops 0-3, see the header)."""
+    dev = require_device(a, b, c, allow_grad=True)
+    a, b = a.detach().contiguous(), b.detach().contiguous()
+    c = c.detach().contiguous() if c is not None else None
+    out0 = torch.empty_like(a)
+    out1 = torch.empty_like(a) if two_outputs else None
+    with torch.cuda.device(dev):
+        st = lib().vcnf_resblock_elementwise_f32(int(op), _ptr(a), _ptr(b), _ptr(c), _ptr(out0), _ptr(out1), a.numel(),
+                                                 _stream())
+    _check(st, "vcnf_resblock_elementwise_f32")
+    return (out0, out1) if two_outputs else out0
 
 
 def channel_mix(z, matrix, shift):

@@ -301,3 +301,62 @@ def linear(mod, x):
             and _lib.lib().vcnf_linear_wgrad_supported(mod.in_features, mod.out_features)):
         return LinearFn.apply(x, mod.weight, mod.bias)
     return mod(x)
+
+def _wgrad_or_torch(x, gy, want_bias=True):
+    if x.shape[0] >= WGRAD_MIN_BATCH and _lib.lib().vcnf_linear_wgrad_supported(x.shape[1], gy.shape[1]):
+        return _lib.linear_wgrad(x, gy, want_bias=want_bias)
+    return gy.t() @ x, (gy.sum(0) if want_bias else None)
+
+
+class ResBlockFn(torch.autograd.Function):
+    """One residual block of the conditioner, out = h + W1 relu(W0 relu(h) + b0) + b1 (times sigmoid(gate) when the
+    block is context-gated; nets/resnet.py:38-57), as ONE autograd node: the GEMMs stay library calls (weight gradients
+    through csrc/linear_wgrad.hip), every elementwise piece of the forward and of the backward is a fused map of
+    csrc/resblock_ops.hip, and only relu(h), relu(a), the second Linear's output and the gate logits are kept."""
+
+    @staticmethod
+    def forward(ctx, h, gate, w0, b0, w1, b1):
+        t0 = torch.relu(h)
+        t1 = torch.relu_(torch.addmm(b0, t0, w0.t()))
+        c = torch.addmm(b1, t1, w1.t())
+        if gate is not None:
+            out = _lib.resblock_op(0, h, c, gate)
+            ctx.save_for_backward(t0, t1, w0, w1, c, gate)
+        else:
+            out = h + c
+            ctx.save_for_backward(t0, t1, w0, w1)
+        ctx.gated = gate is not None
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if ctx.gated:
+            t0, t1, w0, w1, c, gate = ctx.saved_tensors
+            g_c, g_gate = _lib.resblock_op(1, g, c, gate, two_outputs=True)
+        else:
+            t0, t1, w0, w1 = ctx.saved_tensors
+            g_c, g_gate = g.contiguous(), None
+        need = ctx.needs_input_grad
+        gw1, gb1 = _wgrad_or_torch(t1, g_c) if (need[4] or need[5]) else (None, None)
+        g_a = _lib.resblock_op(2, g_c @ w1, t1)
+        gw0, gb0 = _wgrad_or_torch(t0, g_a) if (need[2] or need[3]) else (None, None)
+        g_h = _lib.resblock_op(3, g_a @ w0, t0, g) if need[0] else None
+        return g_h, (g_gate if ctx.gated and need[1] else None), gw0, gb0, gw1, gb1
+
+
+def residual_block(block, inputs, context):
+    """``block(inputs, context)`` through ResBlockFn when the block is the plain training configuration this node
+    covers (ReLU, no batch norm, inactive dropout, fp32 on the GPU, a batch at which the fused maps pay); else None."""
+    from .fused import _is_relu
+    if not (torch.is_grad_enabled() and inputs.is_cuda and inputs.dim() == 2 and inputs.dtype == torch.float32
+            and inputs.shape[0] >= WGRAD_MIN_BATCH and not block.use_batch_norm and _is_relu(block.activation)
+            and not (block.dropout.p > 0 and block.training)):
+        return None
+    l0, l1 = block.linear_layers
+    if not (type(l0) is torch.nn.Linear and type(l1) is torch.nn.Linear and l0.bias is not None and l1.bias is not None):
+        return None
+    if not (inputs.requires_grad or l0.weight.requires_grad or l1.weight.requires_grad):
+        return None
+    gate = linear(block.context_layer, context) if context is not None else None
+    return ResBlockFn.apply(inputs, gate, l0.weight, l0.bias, l1.weight, l1.bias)
