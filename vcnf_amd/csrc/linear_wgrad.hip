@@ -148,7 +148,7 @@ extern "C" int vcnf_linear_wgrad_supported(int32_t in_features, int32_t out_feat
 extern "C" int64_t vcnf_linear_wgrad_slices(int64_t batch, int32_t in_features, int32_t out_features) {
   if (!vcnf_linear_wgrad_supported(in_features, out_features) || batch < 1) return 0;
   const long long row_tiles = (out_features + 127) / 128;
-  long long s = (512 + row_tiles - 1) / row_tiles;
+  long long s = 512 / row_tiles;          // row tiles x slices <= 512 workgroups: two per CU, no third round for a few stragglers
   const long long most = (batch + 255) / 256;
   if (s > most) s = most;
   return s < 1 ? 1 : s;
