@@ -287,6 +287,63 @@ def bench_other(args, device, rank, world):
         dist.destroy_process_group()
 
 
+def bench_train(args, device, rank, world):
+    """Training path of the headline configuration: Adam steps on forward_kld (normflow/core.py:33-45) of the C3 model,
+    131 072 samples per GPU.  Data-parallel over ranks would add a gradient all-reduce; only N = 1 is reported here."""
+    if world != 1:
+        raise SystemExit("--config C3-train reports the single-GPU training step only")
+    B = 131072 if args.batch == 1 << 20 else args.batch
+    torch.manual_seed(0)
+    flows = [nf.flows.CoupledRationalQuadraticSpline(D, BLOCKS, HIDDEN, BINS, tail_bound=TAIL, reverse_mask=bool(i % 2),
+                                                    num_context_channels=CTX) for i in range(LAYERS)]
+    model = nf.NormalizingFlow(nf.distributions.DiagGaussian(D), flows).to(device)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    gen = torch.Generator(device=device).manual_seed(1000)
+    x = torch.randn(B, D, device=device, generator=gen)
+    ctx = torch.randn(B, CTX, device=device, generator=gen)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = model.forward_kld(x, context=ctx)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(max(args.warmup, 1)):
+        step()
+    events = []
+    _lib.EVENT_SINK = events
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.EVENT_SINK = None
+    assert torch.isfinite(loss)
+    durs = [a.elapsed_time(b) * 1e-3 for a, b, t in events if t == "linear_wgrad"]
+    kern_s = sum(durs) / max(len(durs), 1)
+    # algorithmic flop of the weight gradients of one layer's dense layers, averaged over the launches of a layer
+    flop_layer = 2.0 * B * ((D // 2 + CTX) * HIDDEN + 2 * BLOCKS * HIDDEN * HIDDEN + BLOCKS * CTX * HIDDEN
+                            + HIDDEN * (D // 2) * (3 * BINS - 1))
+    launches_layer = 1 + 2 * BLOCKS + BLOCKS + 1
+    per_launch = flop_layer / launches_layer
+    print(json.dumps({
+        "metric": "training samples/sec (Adam step on forward_kld), config C3", "value": round(B * args.steps / dt, 1),
+        "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
+        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C3 model (D=64, 12 RQ-spline couplings, 8 bins, cond_dim=16), Adam step on forward_kld, "
+                               "batch=%d" % B, "batch_per_gpu": B, "layers": LAYERS},
+        "roofline": {"bound": "mfma", "kernel": "linear_wgrad_kernel", "achieved": round(per_launch / kern_s / 1e12, 1) if durs else 0.0,
+                     "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                     "frac": round(per_launch / kern_s / MFMA_F32_PEAK, 4) if durs else 0.0, "traffic": None,
+                     "launches": len(durs), "avg_launch_ms": round(kern_s * 1e3, 4),
+                     "note": "weight / bias gradients of the conditioner's dense layers (exact fp32 matrix instructions, batch "
+                             "reduction split over the chip), averaged over a layer's five shapes; the step also contains "
+                             "library GEMMs (forward, input gradients), the spline forward / VJP kernels and fused "
+                             "elementwise maps"}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -295,10 +352,11 @@ def main():
     ap.add_argument("--batch", type=int, default=1 << 20, help="samples per GPU (weak scaling) or in total (strong)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: every rank holds --batch samples; strong: --batch samples in total, split over the ranks")
-    ap.add_argument("--config", choices=["C3", "C2", "C4", "C5"], default="C3",
+    ap.add_argument("--config", choices=["C3", "C2", "C4", "C5", "C3-train"], default="C3",
                     help="C3 (default) is the headline metric's configuration; C2 (D=32, 8 affine couplings, batch 262144) "
                          "C4 (3x32x32 multiscale Glow, 16384 images per GPU) and C5 (D=1024, 24 RQS couplings, 16 bins, the per-GPU shard 524288) are BASELINE.json's other "
-                         "GPU configurations, reported with their own roofline")
+                         "GPU configurations, reported with their own roofline; C3-train: Adam steps on forward_kld of the C3 model "
+                         "at 131072 samples per GPU (training path, samples/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split", action="store_true",
                     help="three-step layers (gather kernel, torch GEMMs, spline kernel) instead of the fused kernel")
@@ -326,6 +384,8 @@ def main():
         else:
             dist.init_process_group(backend)
     nf.lib()
+    if args.config == "C3-train":
+        return bench_train(args, device, rank, world)
     if args.config != "C3":
         return bench_other(args, device, rank, world)
 
