@@ -174,6 +174,19 @@ int64_t vcnf_resnet_trunk_pack_floats(int32_t d_in, int32_t hidden, int32_t num_
 int vcnf_resnet_trunk_f32(const float* x, float* h, int64_t batch, int32_t d_in, int32_t hidden,
                           int32_t num_blocks, const float* wpack, int64_t wpack_floats, void* stream);
 
+/* The pair with the trunk output handed over already split for the matrix path of the last-layer kernel: row b of
+ * h_split (128 floats wide) holds 128 fp16 hi halves followed by 128 fp16 lo halves (h ~ hi + lo / 2048, values clamped
+ * at +-65504 and counted in sat_count) - the split then happens once per sample instead of once per sample and
+ * feature-group workgroup.  Same results as the fp32 hand-over, bit for bit. */
+int vcnf_resnet_trunk_split_f32(const float* x, float* h_split, int64_t batch, int32_t d_in, int32_t hidden,
+                                int32_t num_blocks, const float* wpack, int64_t wpack_floats, int32_t* sat_count,
+                                void* stream);
+int vcnf_rqs_final_fused_presplit_f32(const float* x, const float* h_split, float* y, float* partial,
+                                      int64_t batch, int32_t features, const int32_t* transform_idx, int32_t d_t,
+                                      int32_t hidden, const float* wpack, int64_t wpack_floats,
+                                      const vcnf_rqs_cfg* cfg, int inverse, int32_t* bad_discriminant, void* stream);
+
+
 /* One RQS coupling layer on x[B,D] -> y[B,D].
  * Replaces Coupling.forward / .inverse (flows/neural_spline/coupling.py:70-96 /
  * :98-125) minus the conditioner call, PiecewiseCoupling._coupling_transform

@@ -1064,6 +1064,12 @@ def test_resnet_trunk_kernel_vs_torch(hip, d_in, blocks):
         scale = float(h64.abs().max())
         e_got, e_ref = float((got.double().cpu() - h64).abs().max()), float((ref32.double().cpu() - h64).abs().max())
         assert e_got <= 2.0 * e_ref + 1e-6 * scale, (d_in, b, e_got, e_ref)
+        # the split hand-over to the last-layer kernel: per row 128 fp16 hi halves | 128 fp16 lo halves of the same values
+        with torch.no_grad():
+            hs = _lib.resnet_trunk(x, fused_final.packed_trunk(m.prqct), 128, blocks, split=True).view(torch.float16).view(b, 256)
+        c = got.clamp(-65504.0, 65504.0)
+        ref_hi = c.half()
+        assert torch.equal(hs[:, :128], ref_hi) and torch.equal(hs[:, 128:], ((c - ref_hi.float()) * 2048.0).half())
 
 
 @pytest.mark.parametrize("k,tails,d,d_id", [(16, "linear", 1024, 512), (8, "linear", 37, 19), (10, "linear", 200, 70),

@@ -88,6 +88,9 @@ PROTOTYPES = {
     "vcnf_resnet_trunk_supported": ([_I32, _I32, _I32], _INT),
     "vcnf_resnet_trunk_pack_floats": ([_I32, _I32, _I32], _I64),
     "vcnf_resnet_trunk_f32": ([_P, _P, _I64, _I32, _I32, _I32, _P, _I64, _P], _INT),
+    "vcnf_resnet_trunk_split_f32": ([_P, _P, _I64, _I32, _I32, _I32, _P, _I64, _P, _P], _INT),
+    "vcnf_rqs_final_fused_presplit_f32": ([_P, _P, _P, _P, _I64, _I32, _P, _I32, _I32, _P, _I64, ctypes.POINTER(RqsCfg), _INT,
+                                           _P, _P], _INT),
     "vcnf_affine_stack_fused_f32": ([_P, _P, _P, _I64, _I32, _I32, _P, _I32, _I32, _I32, _F32, _INT, _P, _I64, _P, _I32,
                                      _INT, _INT, _F32, _P], _INT),
     "vcnf_maf_affine_f32": ([_P, _P, _P, _P, _I64, _I32, _INT, _INT, _F32, _P], _INT),
@@ -524,7 +527,7 @@ def affine_coupling(z, param, t_off, d_t, scale_map, inverse, logdet=None, sign=
     return out, logdet
 
 
-def rqs_final_fused(x, h, out, tf_idx, d_t, hidden, wpack, cfg, inverse, partial=None):
+def rqs_final_fused(x, h, out, tf_idx, d_t, hidden, wpack, cfg, inverse, partial=None, presplit=False):
     """Last conditioner layer + splines (csrc/fused_final.hip): writes out[:, tf_idx], returns the partial
     log-det rows [rows, B] (written into the first rows of ``partial`` when the caller brings the buffer)."""
     dev = require_device(x, h, out, wpack)
@@ -538,10 +541,10 @@ def rqs_final_fused(x, h, out, tf_idx, d_t, hidden, wpack, cfg, inverse, partial
     elif partial.shape[0] < rows or partial.shape[1] != b or not partial.is_contiguous():
         raise VcnfError("partial log-det buffer %s too small for %d rows of %d" % (tuple(partial.shape), rows, b))
     with torch.cuda.device(dev), _timed("rqs_final_fused"):
-        st = lib().vcnf_rqs_final_fused_f32(_ptr(x), _ptr(h), _ptr(out), _ptr(partial), b, d, _ptr(tf_idx), int(d_t),
-                                            int(hidden), _ptr(wpack), wpack.numel(), ctypes.byref(cfg),
-                                            int(bool(inverse)),
-                                            _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
+        fn = lib().vcnf_rqs_final_fused_presplit_f32 if presplit else lib().vcnf_rqs_final_fused_f32
+        st = fn(_ptr(x), _ptr(h), _ptr(out), _ptr(partial), b, d, _ptr(tf_idx), int(d_t), int(hidden), _ptr(wpack),
+                wpack.numel(), ctypes.byref(cfg), int(bool(inverse)),
+                _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
     _check(st, "vcnf_rqs_final_fused_f32")
     return partial
 
@@ -579,15 +582,19 @@ def rqs_identity_half(x, out, id_idx, d_id, shared, cfg, inverse, partial=None, 
     return cond_in
 
 
-def resnet_trunk(x, wpack, hidden, num_blocks):
+def resnet_trunk(x, wpack, hidden, num_blocks, split=False):
     """ResidualNet trunk (initial layer + residual blocks) in one kernel; csrc/resnet_trunk.hip.  x [B, d_in] -> h [B, hidden]."""
     dev = require_device(x, wpack)
     x = x.contiguous()
     b, d_in = x.shape
     h = torch.empty(b, hidden, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), _timed("resnet_trunk"):
-        st = lib().vcnf_resnet_trunk_f32(_ptr(x), _ptr(h), b, int(d_in), int(hidden), int(num_blocks), _ptr(wpack),
-                                         wpack.numel(), _stream())
+        if split:       # h: per row 128 fp16 hi halves | 128 fp16 lo halves, for rqs_final_fused(..., presplit=True)
+            st = lib().vcnf_resnet_trunk_split_f32(_ptr(x), _ptr(h), b, int(d_in), int(hidden), int(num_blocks), _ptr(wpack),
+                                                   wpack.numel(), _ptr(saturation_counter(dev)), _stream())
+        else:
+            st = lib().vcnf_resnet_trunk_f32(_ptr(x), _ptr(h), b, int(d_in), int(hidden), int(num_blocks), _ptr(wpack),
+                                             wpack.numel(), _stream())
     _check(st, "vcnf_resnet_trunk_f32")
     return h
 

@@ -60,7 +60,10 @@ struct FinalShape {
   static_assert(P4 % 2 == 0, "row blocks are processed in pairs");
 };
 
-template <int K, bool INV>
+// PRE: the trunk rows arrive already split (vcnf_resnet_trunk_split_f32: 128 hi halves | 128 lo halves per row), so a
+// wave's B-operand fragments are its loads - the ~100 vector instructions per column block that split fp32 rows (in
+// every one of the feature-group workgroups that read the same row) are gone.
+template <int K, bool INV, bool PRE>
 __global__ __launch_bounds__(kFinBlock, 2) void rqs_final_fused_kernel(const FinalArgs a) {
   using S = FinalShape<K>;
   constexpr int P4 = S::P4, GFRAG = S::GFRAG, GW = S::GW, NS = kFinNS;
@@ -102,13 +105,15 @@ __global__ __launch_bounds__(kFinBlock, 2) void rqs_final_fused_kernel(const Fin
   // the trunk rows of the NEXT column block travel while the current one is processed
   const long long cstride = (long long)a.sblocks * 8;
   float4 nh[2 * NS];
+  // fp32 rows: hidden units 32 s + 8 q .. + 7 are two float4; pre-split rows: the same units' hi halves are the 16 bytes
+  // at half offset 32 s + 8 q, their lo halves 128 halves further
 #define VCNF_FF_FETCH(CB)                                                                   \
   {                                                                                         \
     const long long r_ = (CB) * 16 + m16;                                                   \
-    const float4* hr_ = reinterpret_cast<const float4*>(a.h) + (r_ < a.B ? r_ : 0) * (kFinH / 4) + 2 * q; \
+    const float4* hr_ = reinterpret_cast<const float4*>(a.h) + (r_ < a.B ? r_ : 0) * (kFinH / 4) + (PRE ? q : 2 * q); \
     _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                        \
-      nh[2 * s] = hr_[8 * s];                                                               \
-      nh[2 * s + 1] = hr_[8 * s + 1];                                                       \
+      nh[2 * s] = hr_[PRE ? 4 * s : 8 * s];                                                 \
+      nh[2 * s + 1] = hr_[PRE ? 4 * s + kFinH / 8 : 8 * s + 1];                             \
     }                                                                                       \
   }
   if ((long long)sb * 8 + wave < ncb) {
@@ -121,12 +126,17 @@ __global__ __launch_bounds__(kFinBlock, 2) void rqs_final_fused_kernel(const Fin
     half8 fhi[NS], flo[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const float4 v0 = nh[2 * s], v1 = nh[2 * s + 1];
-      half4 h0, l0, h1, l1;
-      split4<false>(floatx4{v0.x, v0.y, v0.z, v0.w}, h0, l0);
-      split4<false>(floatx4{v1.x, v1.y, v1.z, v1.w}, h1, l1);
-      fhi[s] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-      flo[s] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+      if constexpr (PRE) {
+        fhi[s] = __builtin_bit_cast(half8, nh[2 * s]);
+        flo[s] = __builtin_bit_cast(half8, nh[2 * s + 1]);
+      } else {
+        const float4 v0 = nh[2 * s], v1 = nh[2 * s + 1];
+        half4 h0, l0, h1, l1;
+        split4<false>(floatx4{v0.x, v0.y, v0.z, v0.w}, h0, l0);
+        split4<false>(floatx4{v1.x, v1.y, v1.z, v1.w}, h1, l1);
+        fhi[s] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        flo[s] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
     }
     if (cb + cstride < ncb) {
       VCNF_FF_FETCH(cb + cstride)
@@ -213,26 +223,31 @@ __global__ __launch_bounds__(kFinBlock, 2) void rqs_final_fused_kernel(const Fin
   if (INV && a.bad && bad) atomicAdd(a.bad, 1);
 }
 
-template <int K>
-static int launch_final(const FinalArgs& a, int inverse, hipStream_t st) {
+template <int K, bool PRE>
+static int launch_final_pre(const FinalArgs& a, int inverse, hipStream_t st) {
   using S = FinalShape<K>;
   const size_t lds = (size_t)S::GW * S::GFRAG * 16 + (size_t)S::GW * 16 * S::P4 * sizeof(float);
   static bool attr_set[2] = {false, false};
   if (!attr_set[inverse ? 1 : 0]) {
     hipError_t e = inverse
-        ? hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_final_fused_kernel<K, true>),
+        ? hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_final_fused_kernel<K, true, PRE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-        : hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_final_fused_kernel<K, false>),
+        : hipFuncSetAttribute(reinterpret_cast<const void*>(&rqs_final_fused_kernel<K, false, PRE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return VCNF_ERR_LAUNCH;
     attr_set[inverse ? 1 : 0] = true;
   }
   dim3 grid((unsigned)(a.gblocks * a.sblocks));
   if (inverse)
-    hipLaunchKernelGGL((rqs_final_fused_kernel<K, true>), grid, dim3(kFinBlock), lds, st, a);
+    hipLaunchKernelGGL((rqs_final_fused_kernel<K, true, PRE>), grid, dim3(kFinBlock), lds, st, a);
   else
-    hipLaunchKernelGGL((rqs_final_fused_kernel<K, false>), grid, dim3(kFinBlock), lds, st, a);
+    hipLaunchKernelGGL((rqs_final_fused_kernel<K, false, PRE>), grid, dim3(kFinBlock), lds, st, a);
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
+}
+
+template <int K>
+static int launch_final(const FinalArgs& a, int inverse, bool pre, hipStream_t st) {
+  return pre ? launch_final_pre<K, true>(a, inverse, st) : launch_final_pre<K, false>(a, inverse, st);
 }
 
 static bool final_shape_ok(int d_t, int hidden, int K, int tails) {
@@ -265,10 +280,9 @@ extern "C" int64_t vcnf_rqs_final_fused_partial_rows(int32_t d_t, int32_t num_bi
   return (ng + gw - 1) / gw;
 }
 
-extern "C" int vcnf_rqs_final_fused_f32(const float* x, const float* h, float* y, float* partial,
-                                        int64_t batch, int32_t features, const int32_t* transform_idx, int32_t d_t,
-                                        int32_t hidden, const float* wpack, int64_t wpack_floats,
-                                        const vcnf_rqs_cfg* cfg, int inverse, int32_t* bad_disc, void* stream) {
+static int run_final(const float* x, const float* h, float* y, float* partial, int64_t batch, int32_t features,
+                     const int32_t* transform_idx, int32_t d_t, int32_t hidden, const float* wpack, int64_t wpack_floats,
+                     const vcnf_rqs_cfg* cfg, int inverse, int32_t* bad_disc, bool pre, void* stream) {
   if (!cfg) return VCNF_ERR_NULL;
   if (!final_shape_ok(d_t, hidden, cfg->num_bins, cfg->tails)) return VCNF_ERR_UNSUPPORTED;
   if (batch < 0 || features < d_t) return VCNF_ERR_SHAPE;
@@ -298,5 +312,23 @@ extern "C" int vcnf_rqs_final_fused_f32(const float* x, const float* h, float* y
   c.wh_scale = cfg->wh_scale;
   c.edge_logit = (float)log(exp(1.0 - (double)cfg->min_derivative) - 1.0);
   hipStream_t st = (hipStream_t)stream;
-  return K == 8 ? launch_final<8>(a, inverse, st) : K == 10 ? launch_final<10>(a, inverse, st) : launch_final<16>(a, inverse, st);
+  return K == 8 ? launch_final<8>(a, inverse, pre, st) : K == 10 ? launch_final<10>(a, inverse, pre, st)
+                                                          : launch_final<16>(a, inverse, pre, st);
+}
+
+extern "C" int vcnf_rqs_final_fused_f32(const float* x, const float* h, float* y, float* partial,
+                                        int64_t batch, int32_t features, const int32_t* transform_idx, int32_t d_t,
+                                        int32_t hidden, const float* wpack, int64_t wpack_floats,
+                                        const vcnf_rqs_cfg* cfg, int inverse, int32_t* bad_disc, void* stream) {
+  return run_final(x, h, y, partial, batch, features, transform_idx, d_t, hidden, wpack, wpack_floats, cfg, inverse, bad_disc,
+                   false, stream);
+}
+
+/* the same call on trunk rows that vcnf_resnet_trunk_split_f32 delivered already split into fp16 halves */
+extern "C" int vcnf_rqs_final_fused_presplit_f32(const float* x, const float* h_split, float* y, float* partial,
+                                                 int64_t batch, int32_t features, const int32_t* transform_idx,
+                                                 int32_t d_t, int32_t hidden, const float* wpack, int64_t wpack_floats,
+                                                 const vcnf_rqs_cfg* cfg, int inverse, int32_t* bad_disc, void* stream) {
+  return run_final(x, h_split, y, partial, batch, features, transform_idx, d_t, hidden, wpack, wpack_floats, cfg, inverse,
+                   bad_disc, true, stream);
 }

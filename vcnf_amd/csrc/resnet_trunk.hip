@@ -23,7 +23,8 @@ namespace vcnf {
 
 struct TrunkArgs {
   const float* x;        // [B, d_in] contiguous: (identity features | context)
-  float* h;              // [B, 128]
+  float* h;              // [B, 128] fp32, or (SPLIT) [B][hi 128 halves | lo 128 halves] for csrc/fused_final.hip
+  int32_t* sat;          // SPLIT: counts workgroups that clamped a value at the fp16 range
   const float* wpack;
   unsigned wpack_bytes;
   long long B;
@@ -37,8 +38,9 @@ constexpr int kTH = 128, kTNB = kTH / 16;
 // NT: 16-sample column tiles per wave.  Every weight fragment is a 1 KB load per wave for 4 NT matrix instructions;
 // with one tile the four waves of a CU ask the vector cache for ~128 B per clock, twice what it delivers, so large
 // batches run two tiles per wave (same fragment, two accumulator sets).
-template <int NBLK, int NT>
+template <int NBLK, int NT, bool SPLIT>
 __global__ __launch_bounds__(kTrunkBlock) void resnet_trunk_kernel(const TrunkArgs a) {
+  float satm = 0.f;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,27 +144,44 @@ __global__ __launch_bounds__(kTrunkBlock) void resnet_trunk_kernel(const TrunkAr
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
       if (16 * c + m16 < left) {
-        float* dst = a.h + (b0 + 16 * c + m16) * kTH + 4 * q;
+        if constexpr (!SPLIT) {
+          float* dst = a.h + (b0 + 16 * c + m16) * kTH + 4 * q;
 #pragma unroll
-        for (int nb = 0; nb < kTNB; ++nb) *reinterpret_cast<floatx4*>(dst + 16 * nb) = h[c][nb];
+          for (int nb = 0; nb < kTNB; ++nb) *reinterpret_cast<floatx4*>(dst + 16 * nb) = h[c][nb];
+        } else {
+          // the consumer (last layer + spline kernel) multiplies h as fp16 hi + lo 2^-11 halves: split here, once,
+          // instead of in every one of its feature-group workgroups (same arithmetic as fused_common.hpp::split4)
+          _Float16* row = reinterpret_cast<_Float16*>(a.h + (b0 + 16 * c + m16) * kTH);
+#pragma unroll
+          for (int nb = 0; nb < kTNB; ++nb) {
+            half4 hi, lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) satm = fmaxf(satm, __builtin_fabsf(h[c][nb][r]));
+            split4<false>(h[c][nb], hi, lo);
+            *reinterpret_cast<half4*>(row + 16 * nb + 4 * q) = hi;
+            *reinterpret_cast<half4*>(row + kTH + 16 * nb + 4 * q) = lo;
+          }
+        }
       }
     }
   }
+  if (SPLIT && a.sat && satm > 65504.f) atomicAdd(a.sat, 1);
 }
 
 template <int NBLK, int NT>
-static int launch_trunk_nt(const TrunkArgs& a, hipStream_t st) {
+static int launch_trunk_nt(const TrunkArgs& a, bool split, hipStream_t st) {
   const long long ntiles = (a.B + 64 * NT - 1) / (64 * NT);
   const long long cap = 256 * 8;
   dim3 grid((unsigned)(ntiles < cap ? ntiles : cap));
-  hipLaunchKernelGGL((resnet_trunk_kernel<NBLK, NT>), grid, dim3(kTrunkBlock), 0, st, a);
+  if (split) hipLaunchKernelGGL((resnet_trunk_kernel<NBLK, NT, true>), grid, dim3(kTrunkBlock), 0, st, a);
+  else hipLaunchKernelGGL((resnet_trunk_kernel<NBLK, NT, false>), grid, dim3(kTrunkBlock), 0, st, a);
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }
 
 // two tiles per wave once that still gives every SIMD of the chip a wave (256 CUs x 4 waves x 32 samples)
 template <int NBLK>
-static int launch_trunk(const TrunkArgs& a, hipStream_t st) {
-  return a.B >= 2 * 256 * 4 * 32 ? launch_trunk_nt<NBLK, 2>(a, st) : launch_trunk_nt<NBLK, 1>(a, st);
+static int launch_trunk(const TrunkArgs& a, bool split, hipStream_t st) {
+  return a.B >= 2 * 256 * 4 * 32 ? launch_trunk_nt<NBLK, 2>(a, split, st) : launch_trunk_nt<NBLK, 1>(a, split, st);
 }
 
 }  // namespace vcnf
@@ -178,8 +197,8 @@ extern "C" int64_t vcnf_resnet_trunk_pack_floats(int32_t d_in, int32_t hidden, i
   return (int64_t)kTNB * (d_in / 16) * 256 + kTH + (int64_t)num_blocks * 2 * (kTNB * kTNB * 256 + kTH);
 }
 
-extern "C" int vcnf_resnet_trunk_f32(const float* x, float* h, int64_t batch, int32_t d_in, int32_t hidden,
-                                     int32_t num_blocks, const float* wpack, int64_t wpack_floats, void* stream) {
+static int run_trunk(const float* x, float* h, int64_t batch, int32_t d_in, int32_t hidden, int32_t num_blocks,
+                     const float* wpack, int64_t wpack_floats, bool split, int32_t* sat, void* stream) {
   if (!vcnf_resnet_trunk_supported(d_in, hidden, num_blocks)) return VCNF_ERR_UNSUPPORTED;
   if (batch < 0) return VCNF_ERR_SHAPE;
   if (wpack_floats != vcnf_resnet_trunk_pack_floats(d_in, hidden, num_blocks)) return VCNF_ERR_SHAPE;
@@ -187,9 +206,22 @@ extern "C" int vcnf_resnet_trunk_f32(const float* x, float* h, int64_t batch, in
   if (!x || !h || !wpack) return VCNF_ERR_NULL;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(h)) & 15) return VCNF_ERR_ALIGN;
   TrunkArgs a;
-  a.x = x; a.h = h; a.wpack = wpack; a.wpack_bytes = (unsigned)(wpack_floats * 4); a.B = batch; a.d_in = d_in;
+  a.x = x; a.h = h; a.sat = sat; a.wpack = wpack; a.wpack_bytes = (unsigned)(wpack_floats * 4); a.B = batch; a.d_in = d_in;
   hipStream_t st = (hipStream_t)stream;
-  if (num_blocks == 1) return launch_trunk<1>(a, st);
-  if (num_blocks == 2) return launch_trunk<2>(a, st);
-  return launch_trunk<3>(a, st);
+  if (num_blocks == 1) return launch_trunk<1>(a, split, st);
+  if (num_blocks == 2) return launch_trunk<2>(a, split, st);
+  return launch_trunk<3>(a, split, st);
+}
+
+extern "C" int vcnf_resnet_trunk_f32(const float* x, float* h, int64_t batch, int32_t d_in, int32_t hidden,
+                                     int32_t num_blocks, const float* wpack, int64_t wpack_floats, void* stream) {
+  return run_trunk(x, h, batch, d_in, hidden, num_blocks, wpack, wpack_floats, false, nullptr, stream);
+}
+
+/* same trunk, output already split for vcnf_rqs_final_fused_presplit_f32: row b of `h_split` (128 floats wide) holds 128
+ * fp16 hi halves followed by 128 fp16 lo halves (h ~ hi + lo / 2048, clamped at +-65504 and counted in sat_count) */
+extern "C" int vcnf_resnet_trunk_split_f32(const float* x, float* h_split, int64_t batch, int32_t d_in, int32_t hidden,
+                                           int32_t num_blocks, const float* wpack, int64_t wpack_floats,
+                                           int32_t* sat_count, void* stream) {
+  return run_trunk(x, h_split, batch, d_in, hidden, num_blocks, wpack, wpack_floats, true, sat_count, stream);
 }

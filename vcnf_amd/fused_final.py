@@ -168,12 +168,17 @@ def run(coupling, inputs, context, sampling, log_q=None, sign=1.0):
         else:
             out[:, coupling.identity_features], lad_i = uncond.forward(xi)
     first_in = xi if context is None else torch.cat((xi, context), dim=1)
+    presplit = False
     if coupling.fused_trunk and trunk_eligible(net, first_in, context):
-        h = _lib.resnet_trunk(first_in, packed_trunk(coupling), net.hidden_features, len(net.blocks))
+        # the trunk kernel hands its output over already split into fp16 halves (bit-identical to splitting in the
+        # last-layer kernel, done once per sample instead of once per sample and feature-group workgroup)
+        presplit = True
+        h = _lib.resnet_trunk(first_in, packed_trunk(coupling), net.hidden_features, len(net.blocks), split=True)
     else:
         h = net.hidden(first_in, context)
     partial = _lib.rqs_final_fused(inputs, h, out, coupling._index32('tf'), d_t, net.hidden_features,
-                                   packed_weights(coupling), coupling._cfg(True), sampling, partial=partial)
+                                   packed_weights(coupling), coupling._cfg(True), sampling, partial=partial,
+                                   presplit=presplit)
     lad = partial.sum(0) if partial.shape[0] > 1 else partial[0]
     if lad_i is not None:
         lad = lad + lad_i
