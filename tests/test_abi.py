@@ -139,6 +139,10 @@ def test_validation_status_codes_of_the_round2_entry_points():
     n = L.vcnf_resnet_trunk_pack_floats(512, 128, 2)
     assert n == 8 * 32 * 256 + 128 + 2 * 2 * (64 * 256 + 128)
     assert L.vcnf_resnet_trunk_f32(fake, fake, 4, 512, 128, 2, fake, n - 1, None) == 2
+    assert L.vcnf_resnet_trunk_split_f32(fake, fake, 4, 512, 128, 2, fake, n - 1, None, None) == 2
+    assert L.vcnf_resnet_trunk_split_f32(fake, fake, 0, 512, 128, 2, fake, n, None, None) == 0
+    assert L.vcnf_rqs_final_fused_presplit_f32(fake, fake, fake, fake, 4, 1024, fake, 512, 128, fake, 7, ctypes.byref(cfg), 0, None,
+                                               None) == 2          # packed size mismatch
     # channel mix: multiples of 4 up to 64
     assert [L.vcnf_channel_mix_supported(c) for c in (4, 6, 48, 64, 68)] == [1, 0, 1, 1, 0]
     assert L.vcnf_channel_mix_f32(fake, fake, fake, fake, 2, 6, 16, None) == 5
