@@ -24,6 +24,11 @@ The JSON line also carries
                  matrix instructions per product) or the fp32 matrix peak (--precision fp32).  --split: the
                  HBM-bound spline kernel, 3464 algorithmic bytes per sample-layer against 8 TB/s (and against
                  the measured 6.3 TB/s copy rate, frac_of_measured_copy_bw);
+  other_matrix_path - the fused kernel's other matrix arithmetic on the same workload, timed exactly like the
+                 headline: the same --warmup untimed steps, the same --steps timed steps, fenced by barrier +
+                 synchronize on both sides, max over ranks;
+  extra_configs - (N = 1, unless --no-extra) BASELINE.json's other GPU configurations C2 / C4 / C5 and the C3
+                 training step, 1 warm-up + 2 timed steps each, each with its own ms_per_step, dtype and roofline;
   cpu_baseline - the CPU oracle (op-order-faithful PyTorch-CPU restatement of the reference path) timed on this
                  box's host cores on a bounded sample of the same workload: 1 warm-up + 3 timed runs, median
                  (rank 0, N=1 only).  Reported, not a target.
@@ -147,11 +152,17 @@ def cpu_baseline(model, budget_s=20.0):
                       % (b, t, ts[0], ts[2], cores)}
 
 
-def bench_other(args, device, rank, world):
-    """BASELINE.json's configurations C2, C4 and C5 (one line each, same schema; not the headline metric)."""
+def bench_other(args, device, rank, world, config=None, steps=None, warmup=None, cpu=True):
+    """BASELINE.json's configurations C2, C4 and C5 (same schema as the headline line; not the headline metric).
+    Returns the result dict on rank 0 (None elsewhere).  Weak scaling only: every rank holds the per-GPU batch."""
     from vcnf_amd.sharded import max_over_ranks
+    config = config or args.config
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    if args.scaling != "weak":
+        raise SystemExit("--config %s is reported per GPU (weak scaling) only" % config)
     torch.manual_seed(0)
-    if args.config == "C2":
+    if config == "C2":
         d, layers, B = 32, 8, 262144 if args.batch == 1 << 20 else args.batch
         flows = []
         for _ in range(layers):
@@ -164,7 +175,7 @@ def bench_other(args, device, rank, world):
         hbm_bytes = 4 * d * 2 + 8                                             # x once, y once, log_q
         workload = "C2: tabular D=32, 8 affine couplings (MLP 16-64-64-32) + swap permutations, batch=%d per GPU" % B
         dtype = "f32"
-    elif args.config == "C4":
+    elif config == "C4":
         d, layers, B = 3072, 48, 16384 if args.batch == 1 << 20 else args.batch
         levels = [(48, 4, 4), (24, 8, 8), (12, 16, 16)]
         q0, merges, flows = [], [], []
@@ -174,14 +185,20 @@ def bench_other(args, device, rank, world):
             if i > 0:
                 merges += [nf.flows.Merge()]
             q0 += [nf.distributions.DiagGaussian(shape if i == 0 else (shape[0] // 2,) + shape[1:])]
-        tag, kname = "channel_mix", "channel_mix_kernel"
-        bytes_sl = 8 * sum(c * h * w for c, h, w in levels) // 3              # average over the three levels' launches
-        work, peak, unit, bound = bytes_sl, HBM_PEAK, "GB/s", "hbm"
+        # dominant kernel: the whole ConvNet2d conditioner of a GlowBlock (3x3 -> 1x1 -> nine tap matrices of the last
+        # 3x3 convolution) in one launch, csrc/conv3x3_1x1.hip, on fp16 split-half operands.  Algorithmic flop per image
+        # and launch at level (c, h, w): h w 2 (9 (c/2) 256 + 256 256 + 9 c 256); one launch per block and direction
+        tag, kname = "convnet3_taps", "conv3x3_1x1_f16x3_kernel"
+        flop_img = [hh * ww * 2 * (9 * (c // 2) * 256 + 256 * 256 + 9 * c * 256) for c, hh, ww in levels]
+        work, peak, unit, bound = sum(flop_img) / 3.0, MFMA_F16_PEAK / 3.0, "TFLOP/s", "mfma"    # average launch
+        bytes_sl = 0
         hbm_bytes = None
         workload = ("C4: 3 x 32 x 32 images, multiscale Glow (3 levels x 16 GlowBlocks, 256 hidden channels), batch=%d per "
-                    "GPU; the conv conditioners are MIOpen calls (they dominate the step), affine couplings and the "
-                    "1x1 convolution + ActNorm mixers are this repository's kernels" % B)
-        dtype = "f32"
+                    "GPU; every kernel of the step is this repository's: the conv conditioner (3x3, 1x1, 3x3 convolutions) "
+                    "of a block is one matrix-core launch + a shift-and-add launch, affine coupling, 1x1 convolution + "
+                    "ActNorm mixers" % B)
+        dtype = ("f32 (conv conditioner: fp16x3 split operands, 22-bit hi + lo fp16 halves, three matrix instructions per "
+                 "product, fp32 accumulate, saturation counted; couplings and mixers fp32)")
     else:
         d, layers, B = 1024, 24, 524288 if args.batch == 1 << 20 else args.batch
         flows = [nf.flows.CoupledRationalQuadraticSpline(d, 2, 128, 16, reverse_mask=bool(i % 2)) for i in range(layers)]
@@ -193,7 +210,7 @@ def bench_other(args, device, rank, world):
                     "(the per-GPU shard of the 4M batch is 524288; the conditioner logits never exist in memory, so the "
                     "shard is one pass)" % B)
         dtype = "f32 (last conditioner layer: fp16x3 split operands, fp32 accumulate; trunk fp32)"
-    if args.config == "C4":
+    if config == "C4":
         model = nf.MultiscaleFlow(q0, flows, merges, class_cond=False).to(device).eval()
     else:
         model = nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows).to(device).eval()
@@ -204,7 +221,7 @@ def bench_other(args, device, rank, world):
             if n.endswith("param_map.net.4.weight") or n.endswith("param_map.net.4.bias"):
                 p.normal_(0.0, 0.02)          # Glow's zero-initialised last convolution would make every coupling the identity
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
-    if args.config == "C4":
+    if config == "C4":
         x = torch.rand(B, 3, 32, 32, device=device, generator=gen)
         eps = [torch.randn(B, *q.loc.shape[1:], device=device, generator=gen) for q in model.q0]
         with torch.no_grad():
@@ -221,31 +238,35 @@ def bench_other(args, device, rank, world):
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
     with torch.no_grad():
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
         events = []
         _lib.EVENT_SINK = events
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             stats, lq = step()
         fence()
         dt = max_over_ranks(time.perf_counter() - t0, device)
         _lib.EVENT_SINK = None
     nf.check_discriminant(device)
+    # C4 (conditioner) and C5 (trunk hand-over, last layer) run on clamping split-half operands: nothing may have clamped
+    saturated = nf.check_saturation(device, model=model)
+    assert saturated == 0, "a split-half matrix path clamped values in %d workgroup(s)" % saturated
     assert torch.isfinite(stats).all() and torch.isfinite(lq).all()
     durs = [a.elapsed_time(b) * 1e-3 for a, b, t in events if t == tag]
     kern_s = sum(durs) / max(len(durs), 1)
     per_launch = work * B
     scale = 1e9 if unit == "GB/s" else 1e12
+    out = None
     if rank == 0:
-        out = {"metric": "flow transforms/sec (log_prob + sample), config %s" % args.config,
-               "value": round(2.0 * B * world * args.steps / dt, 1), "unit": "transforms/s", "n_gpus": world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+        out = {"metric": "flow transforms/sec (log_prob + sample), config %s" % config,
+               "value": round(2.0 * B * world * steps / dt, 1), "unit": "transforms/s", "n_gpus": world,
+               "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "config": {"workload": workload, "batch_per_gpu": B, "layers": layers},
                "roofline": {"bound": bound, "kernel": kname, "achieved": round(per_launch / kern_s / scale, 1) if durs else 0.0,
@@ -255,14 +276,23 @@ def bench_other(args, device, rank, world):
                             "algorithmic_work_per_launch": per_launch,
                             "note": ("algorithmic flop %d per sample-layer x %d layers per launch (MLP conditioners on "
                                      "v_mfma_f32_16x16x4_f32); HBM side of a launch: %d B per sample (%.1f us at 8 TB/s)"
-                                     % (flop_sl, layers, hbm_bytes, 1e6 * hbm_bytes * B / HBM_PEAK)) if args.config == "C2" else
-                                    ("1x1 convolution + ActNorm of a GlowBlock as one channel map: read + write of the level's "
-                                     "activations, %d B per sample on average over the three levels; the step itself is "
-                                     "dominated by the conditioners' library convolutions" % bytes_sl) if args.config == "C4" else
+                                     % (flop_sl, layers, hbm_bytes, 1e6 * hbm_bytes * B / HBM_PEAK)) if config == "C2" else
+                                    ("the GlowBlock conditioner (conv3x3 -> 1x1 -> nine tap matrices of the last conv3x3) as "
+                                     "one launch: %.1f MFLOP per image and launch averaged over the three levels "
+                                     "(%s), against the dense f16 matrix peak / 3 (split-half operands); it is ~3/4 of "
+                                     "the step.  SURVEY 8d's coupling-only yardstick for C4 (688 512 B per transform) "
+                                     "would be %.2f ms per step at 8 TB/s" % (
+                                         work / 1e6, " / ".join("%.1f" % (f / 1e6) for f in flop_img),
+                                         1e3 * 2 * 688512.0 * B / HBM_PEAK)) if config == "C4" else
                                     ("operator-boundary bytes %d per sample-layer (x + the [d_t, 3K-1] logits + y + log_q, "
                                      "SURVEY 8d) per launch of the last-layer + spline kernel; the logits never reach "
-                                     "HBM in this path, so this is the yardstick, not the traffic" % bytes_sl)}}
-        if world == 1 and not args.no_cpu_baseline and args.config == "C2":
+                                     "HBM in this path, so this is the yardstick, not the traffic; as matrix work the same "
+                                     "launch is %.2f MFLOP per sample on split-half operands: %.3f of the f16 peak / 3"
+                                     % (bytes_sl, 2 * 128 * 512 * 47 / 1e6,
+                                        (2.0 * 128 * 512 * 47 * B / kern_s) / (MFMA_F16_PEAK / 3.0) if durs else 0.0))}}
+        if config == "C5":
+            out["whole_step_frac_of_yardstick"] = round(2 * layers * bytes_sl * B / HBM_PEAK / (dt / steps), 4)
+        if world == 1 and cpu and not args.no_cpu_baseline and config == "C2":
             from helpers import oracle_affine_stack
             sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             stack = oracle_affine_stack(sd, layers, d)
@@ -281,17 +311,18 @@ def bench_other(args, device, rank, world):
             out["cpu_baseline"] = {"value": round(2 * B / ts[1], 1), "unit": "transforms/s", "cores": cores, "kind": "port",
                                    "sample": "oracle C2 stack at the full batch %d, 1 warm-up + 3 timed runs, median %.2f s, "
                                              "torch CPU fp32, %d threads" % (B, ts[1], cores)}
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    del model, x, eps
+    torch.cuda.empty_cache()
+    return out
 
 
-def bench_train(args, device, rank, world):
+def bench_train(args, device, rank, world, steps=None, warmup=None):
     """Training path of the headline configuration: Adam steps on forward_kld (normflow/core.py:33-45) of the C3 model,
     131 072 samples per GPU.  Data-parallel over ranks would add a gradient all-reduce; only N = 1 is reported here."""
     if world != 1:
         raise SystemExit("--config C3-train reports the single-GPU training step only")
+    steps = steps or args.steps
+    warmup = max(args.warmup if warmup is None else warmup, 1)
     B = 131072 if args.batch == 1 << 20 else args.batch
     torch.manual_seed(0)
     flows = [nf.flows.CoupledRationalQuadraticSpline(D, BLOCKS, HIDDEN, BINS, tail_bound=TAIL, reverse_mask=bool(i % 2),
@@ -308,13 +339,13 @@ def bench_train(args, device, rank, world):
         loss.backward()
         opt.step()
         return loss
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(warmup):
         step()
     events = []
     _lib.EVENT_SINK = events
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -327,10 +358,10 @@ def bench_train(args, device, rank, world):
                             + HIDDEN * (D // 2) * (3 * BINS - 1))
     launches_layer = 1 + 2 * BLOCKS + BLOCKS + 1
     per_launch = flop_layer / launches_layer
-    print(json.dumps({
-        "metric": "training samples/sec (Adam step on forward_kld), config C3", "value": round(B * args.steps / dt, 1),
-        "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
-        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+    out = {
+        "metric": "training samples/sec (Adam step on forward_kld), config C3", "value": round(B * steps / dt, 1),
+        "unit": "samples/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(1e3 * dt / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C3 model (D=64, 12 RQ-spline couplings, 8 bins, cond_dim=16), Adam step on forward_kld, "
                                "batch=%d" % B, "batch_per_gpu": B, "layers": LAYERS},
@@ -341,7 +372,35 @@ def bench_train(args, device, rank, world):
                      "note": "weight / bias gradients of the conditioner's dense layers (exact fp32 matrix instructions, batch "
                              "reduction split over the chip), averaged over a layer's five shapes; the step also contains "
                              "library GEMMs (forward, input gradients), the spline forward / VJP kernels and fused "
-                             "elementwise maps"}}))
+                             "elementwise maps"}}
+    del model, opt, x, ctx
+    torch.cuda.empty_cache()
+    return out
+
+
+def extra_configs(args, device):
+    """Short legs of BASELINE.json's other GPU configurations and of the training step, for the default JSON line
+    (N = 1): 1 warm-up + 2 timed steps each, so that every configuration's figure is driver-visible."""
+    out = {}
+    for cfg in ("C2", "C4", "C5"):
+        r = bench_other(args, device, 0, 1, config=cfg, steps=2, warmup=1, cpu=False)
+        out[cfg] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline")
+                    if k in r}
+        if "whole_step_frac_of_yardstick" in r:
+            out[cfg]["whole_step_frac_of_yardstick"] = r["whole_step_frac_of_yardstick"]
+    r = bench_train(args, device, 0, 1, steps=2, warmup=1)
+    out["C3-train"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline")}
+    return out
+
+
+DTYPE = {
+    "fp16x3": ("f32 results on fp16x3 split operands: every fp32 operand of a conditioner GEMM travels as hi + lo fp16 "
+               "halves, three f16 matrix instructions per product, fp32 accumulation; GEMM error measured at or below "
+               "the exact-fp32 matrix path's on every C3 layer shape (tests/test_gpu_gemm_error.py); values beyond "
+               "the fp16 range are re-evaluated on the exact fp32 path on the device (never clamped)"),
+    "fp32": "f32 (exact fp32 matrix instructions v_mfma_f32_16x16x4_f32)",
+    "split": "f32",
+}
 
 
 def main():
@@ -358,11 +417,13 @@ def main():
                          "GPU configurations, reported with their own roofline; C3-train: Adam steps on forward_kld of the C3 model "
                          "at 131072 samples per GPU (training path, samples/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs (C2 / C4 / C5 / C3-train) of the default line")
     ap.add_argument("--split", action="store_true",
                     help="three-step layers (gather kernel, torch GEMMs, spline kernel) instead of the fused kernel")
     ap.add_argument("--precision", choices=["fp16x3", "fp32"], default="fp16x3",
-                    help="matrix path of the fused layer kernel: fp16 split-half (22-bit operands, fp32 "
-                         "accumulation; default) or exact fp32 matrix instructions")
+                    help="matrix path of the fused layer kernel whose figure is `value`: fp16 split-half operands with "
+                         "fp32 accumulation and device-side fp32 re-evaluation of out-of-range tiles (default), or exact "
+                         "fp32 matrix instructions; the other one is timed the same way and reported as other_matrix_path")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -377,7 +438,13 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # A launcher (torch.distributed.run) sets RANK / WORLD_SIZE / MASTER_*: the process group is then initialised for
+    # EVERY world size, one rank included, so that `torchrun --nproc-per-node 1 bench.py --gpus 1` runs the same RCCL
+    # calls (barrier fencing, the fp64 [sum log_prob, count] all-reduce, the MAX of the timings) as an N-rank job.
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if launched:
+        # this pool's host driver supports dmabuf IPC only: without the variable RCCL's (and torch's) cross-process
+        # buffer sharing fails with hipIpcGetMemHandle: invalid argument (environment note of the GPU boxes)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -385,17 +452,24 @@ def main():
             dist.init_process_group(backend)
     nf.lib()
     if args.config == "C3-train":
-        return bench_train(args, device, rank, world)
+        print(json.dumps(bench_train(args, device, rank, world)))
+        return
     if args.config != "C3":
-        return bench_other(args, device, rank, world)
+        out = bench_other(args, device, rank, world)
+        if rank == 0:
+            print(json.dumps(out))
+        if launched:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     model = build_model(device, seed=0)                      # replicated weights
+
     def route(split, precision):
         for f in model.flows:
             f.prqct.fused = not split
             f.prqct.fused_precision = precision
-    route(args.split, args.precision)
-    from vcnf_amd.sharded import bench_shard
+    from vcnf_amd.sharded import bench_shard, max_over_ranks
     B, seed = bench_shard(args.batch, args.scaling, rank, world)     # this rank's samples and data seed
     gen = torch.Generator(device=device).manual_seed(seed)
     x = torch.randn(B, D, device=device, generator=gen)
@@ -411,22 +485,34 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_region(split, precision):
+        """--warmup untimed steps, then exactly --steps steps between two fences; whole-job time = max over ranks.
+        Returns (seconds, per-launch HIP-event durations of the layer kernel inside the region)."""
+        route(split, precision)
+        with torch.no_grad():
+            for _ in range(args.warmup):
+                step()
+            events = []
+            _lib.EVENT_SINK = events
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                stats, z, lq = step()
+            fence()
+            dt = time.perf_counter() - t0
+            _lib.EVENT_SINK = None
+        nf.check_discriminant(device)
+        assert torch.isfinite(stats).all() and torch.isfinite(lq).all()
+        return max_over_ranks(dt, device), [a.elapsed_time(b) * 1e-3 for a, b, _ in events]
+
+    head = "split" if args.split else args.precision
+    dt, durs = timed_region(args.split, args.precision)
+    redone = nf.range_redo_count(device)                     # tiles the split-half kernel handed to the exact fp32 path
     with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        events = []
-        _lib.EVENT_SINK = events
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            stats, z, lq = step()
-        fence()
-        dt = time.perf_counter() - t0
-        _lib.EVENT_SINK = None
         # the two directions on their own (outside the timed region): rates + harmonic combination, SURVEY 8d
         def timed(fn, n=2):
             fn()
@@ -436,45 +522,49 @@ def main():
                 fn()
             fence()
             return (time.perf_counter() - t1) / n
-        dt_lp = timed(lambda: evaluator.reduce_stats(model.log_prob(x, ctx)))
-        dt_sm = timed(lambda: model.sample_from(eps, ctx))
-    nf.check_discriminant(device)
-    saturated = nf.check_saturation(device, model=model)     # fp16 split-half path: any value clamped at +-65504?
-    assert saturated == 0, "the split-half matrix path clamped values in %d workgroup(s)" % saturated
-    assert torch.isfinite(stats).all() and torch.isfinite(lq).all()
+        dt_lp = max_over_ranks(timed(lambda: evaluator.reduce_stats(model.log_prob(x, ctx))), device)
+        dt_sm = max_over_ranks(timed(lambda: model.sample_from(eps, ctx)), device)
 
-    from vcnf_amd.sharded import max_over_ranks
-    dt = max_over_ranks(dt, device)
-    dt_lp = max_over_ranks(dt_lp, device)
-    dt_sm = max_over_ranks(dt_sm, device)
     total = torch.tensor([float(B)], dtype=torch.float64, device=device)     # samples of the whole job
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(total)
     total = float(total.item())
 
-    # dominant kernel: mean launch duration inside the timed region (HIP events on the launch stream).
-    # Fused layers: one kernel per layer does conditioner + splines and is bound by the fp32 matrix
-    # cores; split layers: the spline kernel streams params from HBM and is HBM-bound.
-    durs = [a.elapsed_time(b) * 1e-3 for a, b, _ in events]
-    kern_s = sum(durs) / max(len(durs), 1)
-    if args.split:
-        work, peak, unit, bound, kname = BYTES_PER_SAMPLE_LAYER * B, HBM_PEAK, "GB/s", "hbm", "rqs_coupling_pf_kernel"
-        note = "algorithmic bytes 3464 B/sample-layer (x + params + y + logdet)"
-    elif args.precision == "fp32":
-        work, peak, unit, bound, kname = FLOP_PER_SAMPLE_LAYER * B, MFMA_F32_PEAK, "TFLOP/s", "mfma", "fused_rqs_layer_kernel"
-        note = ("algorithmic flop %d per sample-layer (conditioner GEMMs) on v_mfma_f32_16x16x4_f32; HBM side of "
-                "the same launch: %d B/sample-layer" % (FLOP_PER_SAMPLE_LAYER, 4 * D + 4 * CTX + 4 * D + 8))
-    else:
-        # split-half path: every product costs three f16 matrix instructions, so the ceiling for
-        # algorithmic flop is a third of the dense f16 peak
-        work, peak, unit, bound, kname = (FLOP_PER_SAMPLE_LAYER * B, MFMA_F16_PEAK / 3.0, "TFLOP/s", "mfma",
-                                          "fused_rqs_layer_v6_kernel")
-        note = ("algorithmic flop %d per sample-layer (conditioner GEMMs); peak = dense f16 matrix peak / 3 "
-                "(hi*hi + hi*lo + lo*hi per product, 22-bit operands, fp32 accumulation); HBM side of the same "
-                "launch: %d B/sample-layer" % (FLOP_PER_SAMPLE_LAYER, 4 * D + 4 * CTX + 4 * D + 8))
-    achieved = work / kern_s if durs else 0.0
-    scale = 1e9 if unit == "GB/s" else 1e12
-    traffic = pmc_traffic(kname, B)
+    def roofline_of(path, durs):
+        """Dominant kernel of a timed region: mean launch duration (HIP events on the launch stream) against the
+        ceiling of its matrix arithmetic (fused layers) or HBM (three-step layers)."""
+        kern_s = sum(durs) / max(len(durs), 1)
+        if path == "split":
+            work, peak, unit, bound, kname = BYTES_PER_SAMPLE_LAYER * B, HBM_PEAK, "GB/s", "hbm", "rqs_coupling_pf_kernel"
+            note = "algorithmic bytes 3464 B/sample-layer (x + params + y + logdet)"
+        elif path == "fp32":
+            work, peak, unit, bound, kname = FLOP_PER_SAMPLE_LAYER * B, MFMA_F32_PEAK, "TFLOP/s", "mfma", "fused_rqs_layer_kernel"
+            note = ("algorithmic flop %d per sample-layer (conditioner GEMMs) on v_mfma_f32_16x16x4_f32; HBM side of "
+                    "the same launch: %d B/sample-layer" % (FLOP_PER_SAMPLE_LAYER, 4 * D + 4 * CTX + 4 * D + 8))
+        else:
+            # split-half path: every product costs three f16 matrix instructions, so the ceiling for
+            # algorithmic flop is a third of the dense f16 peak
+            work, peak, unit, bound, kname = (FLOP_PER_SAMPLE_LAYER * B, MFMA_F16_PEAK / 3.0, "TFLOP/s", "mfma",
+                                              "fused_rqs_layer_v6_kernel")
+            note = ("algorithmic flop %d per sample-layer (conditioner GEMMs); peak = dense f16 matrix peak / 3 "
+                    "(hi*hi + hi*lo + lo*hi per product, fp32 accumulation); HBM side of the same "
+                    "launch: %d B/sample-layer" % (FLOP_PER_SAMPLE_LAYER, 4 * D + 4 * CTX + 4 * D + 8))
+        achieved = work / kern_s if durs else 0.0
+        scale = 1e9 if unit == "GB/s" else 1e12
+        return {"bound": bound, "kernel": kname, "achieved": round(achieved / scale, 1), "peak": peak / scale, "unit": unit,
+                "frac": round(achieved / peak, 4), "traffic": pmc_traffic(kname, B), "launches": len(durs),
+                "avg_launch_ms": round(kern_s * 1e3, 4), "algorithmic_work_per_launch": work, "note": note}
+
+    # the other matrix path of the fused kernel: same workload, same warm-up, same steps, same fences
+    other = None
+    if not args.split:
+        alt = "fp32" if args.precision == "fp16x3" else "fp16x3"
+        dt_alt, durs_alt = timed_region(False, alt)
+        redone += nf.range_redo_count(device)
+        other = {"matrix_path": alt, "dtype": DTYPE[alt], "value": round(2.0 * total * args.steps / dt_alt, 1),
+                 "unit": "transforms/s", "ms_per_step": round(1e3 * dt_alt / args.steps, 3), "steps": args.steps,
+                 "warmup": args.warmup, "roofline": roofline_of(alt, durs_alt)}
+        route(args.split, args.precision)
 
     # the HBM-bound spline kernel on its own (outside the timed region): one layer evaluated
     # through the three-step path with the conditioner output materialised, spline launch timed
@@ -501,23 +591,7 @@ def main():
                     "frac_of_measured_copy_bw": round(BYTES_PER_SAMPLE_LAYER * B / t_sp / HBM_COPY, 4),
                     "avg_launch_ms": round(t_sp * 1e3, 4)}
 
-    # the other matrix path of the fused kernel, same workload, outside the timed region
-    other = None
-    if rank == 0 and world == 1 and not args.split:
-        alt = "fp32" if args.precision == "fp16x3" else "fp16x3"
-        route(False, alt)
-        with torch.no_grad():
-            step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-            dt_alt = (time.perf_counter() - t1) / 2
-        route(args.split, args.precision)
-        other = {"matrix_path": alt + (" (exact fp32 matrix instructions)" if alt == "fp32" else ""),
-                 "value": round(2.0 * B / dt_alt, 1), "unit": "transforms/s", "ms_per_step": round(1e3 * dt_alt, 3)}
-
+    out = None
     if rank == 0:
         transforms = 2.0 * total * args.steps
         out = {
@@ -527,33 +601,38 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": ("f32 (fp16x3 split operands: 22-bit hi + lo fp16 halves, three matrix instructions per product, "
-                      "fp32 accumulate; saturation counted)" if (args.precision == "fp16x3" and not args.split) else "f32"),
+            "dtype": DTYPE[head],
             "data": "synthetic",
             "log_prob_rate": round(total / dt_lp, 1), "sample_rate": round(total / dt_sm, 1),
             "harmonic_rate": round(2.0 * total / (dt_lp + dt_sm), 1),
+            "frac_of_hbm_roofline_end_to_end": round(2 * LAYERS * BYTES_PER_SAMPLE_LAYER * B / HBM_PEAK / (dt / args.steps), 4),
             "config": {"workload": "C3: conditional D=64 (cond_dim=16), 12 RQ-spline coupling layers "
                                    "(8 bins), batch=%d per GPU, log_prob + sample per step" % B,
                        "batch_per_gpu": B, "batch_total": int(total), "layers": LAYERS, "bins": BINS, "hidden": HIDDEN,
+                       "matrix_path": head, "range_redo_tiles": int(redone),
+                       "process_group": ("%s, %d rank(s)" % (dist.get_backend(), world)) if dist.is_initialized() else "none",
                        "sharding": "%s scaling: %s over %d GPU(s) (contiguous shards, weights replicated), one "
                                    "all-reduce of [sum log_prob, count] per log_prob" % (
                                        args.scaling, ("%d samples per GPU" % B) if args.scaling == "weak" else
                                        ("%d samples in total" % int(total)), world)},
-            "roofline": {"bound": bound, "kernel": kname,
-                         "achieved": round(achieved / scale, 1), "peak": peak / scale, "unit": unit,
-                         "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "launches": len(durs), "avg_launch_ms": round(kern_s * 1e3, 4),
-                         "algorithmic_work_per_launch": work, "note": note},
+            "roofline": roofline_of(head, durs),
         }
         if hbm_side is not None:
             out["roofline_hbm_spline_kernel"] = hbm_side
         if other is not None:
             out["other_matrix_path"] = other
-        out["config"]["matrix_path"] = "split (torch GEMMs)" if args.split else args.precision
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(model)
+    del model, x, ctx, eps, evaluator
+    torch.cuda.empty_cache()
+    if rank == 0:
+        if world == 1 and not args.no_extra:
+            out["extra_configs"] = extra_configs(args, device)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 

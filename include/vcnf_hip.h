@@ -335,15 +335,24 @@ int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t ctx_dim, i
  * ctx_dim = 0.  x, y, context must be 16-byte aligned.
  * precision: VCNF_PREC_F32 - every dense layer on v_mfma_f32_16x16x4_f32 (exact fp32
  * fma chains); VCNF_PREC_F16X3 - every dense layer on v_mfma_f32_32x32x16_f16 with both
- * operands split into hi + lo*2^-11 fp16 halves (22 significant bits, 3 instructions
- * per product, fp32 accumulation).  The split clamps at +-65504: inputs, context and
- * hidden activations beyond that are NOT represented; sat_count (device int32, may be
- * NULL) is incremented by every workgroup that clamped a value, so the caller can
- * detect it and re-run with VCNF_PREC_F32 (the reference is plain fp32,
- * nets/resnet.py:92-106).  wpack must have been packed for the same precision; the
- * F16X3 buffer has the 1/sqrt(hidden) logit scale (coupling.py:314-316) and the
- * log2(e) factors of the softmax / softplus / sigmoid exponentials folded in
- * (vcnf_amd/fused.py::pack_layer_h3), cfg->wh_scale must be the folded value. */
+ * operands split into hi + lo*2^-11 fp16 halves (3 instructions per product, 4 in the
+ * 16- and 48-deep layers, fp32 accumulation; GEMM error at or below the F32 path's on
+ * every layer shape, tests/test_gpu_gemm_error.py).  The halves cannot carry a value
+ * beyond +-65504 or a non-finite input.  redo_tiles (device int32, one entry per
+ * vcnf_rqs_layer_fused_tile_rows() = 128 consecutive samples, may be NULL) makes the pair
+ * of calls below range-safe WITHOUT a host round trip:
+ *   F16X3 call: redo_tiles is OUTPUT - 1 for a tile that held such a value, and then no
+ *     y row and no logdet entry of that tile is written; 0 otherwise.
+ *   F32 call with the same arguments (and the F32 packing of the same weights):
+ *     redo_tiles is INPUT - only the flagged tiles are evaluated.
+ * After both, every sample has fp32-range results (the reference is plain fp32,
+ * nets/resnet.py:92-106).  With redo_tiles == NULL the F16X3 call clamps at +-65504 and
+ * stores.  sat_count (device int32, may be NULL) is incremented once per out-of-range tile
+ * in either case.  wpack must have been packed for the same precision; the F16X3 buffer
+ * has the 1/sqrt(hidden) logit scale (coupling.py:314-316) and the log2(e) factors of the
+ * softmax / softplus / sigmoid exponentials folded in (vcnf_amd/fused.py::pack_layer_h3),
+ * cfg->wh_scale must be the folded value. */
+int32_t vcnf_rqs_layer_fused_tile_rows(void);
 int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, float* logdet,
                              int64_t batch, const int32_t* transform_idx, int32_t d_t,
                              const int32_t* identity_idx, int32_t d_id, int32_t ctx_dim,
@@ -352,7 +361,7 @@ int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, flo
                              const float* shared_w, const float* shared_h, const float* shared_d,
                              const vcnf_rqs_cfg* cfg, int inverse,
                              int ld_mode, float ld_sign, int32_t* bad_disc, int32_t* sat_count,
-                             void* stream);
+                             int32_t* redo_tiles, void* stream);
 
 /* Affine coupling on z[B, C, inner] (inner = H*W, 1 for 2-D inputs).
  * Replaces AffineCoupling.forward / .inverse (flows/affine/coupling.py:113-142 /
@@ -425,6 +434,19 @@ int vcnf_diag_gaussian_log_prob_f32(const float* z, const float* loc, const floa
 int vcnf_diag_gaussian_sample_f32(const float* eps, const float* loc, const float* log_scale,
                                   float log_temperature, float* z, float* logp, int64_t batch,
                                   int32_t features, void* stream);
+
+/* Diagnostic, not on any product path: ONE dense layer y[B, N] = x[B, K] W[N, K]^T + b (nn.Linear,
+ * nets/resnet.py:78-106) evaluated with the arithmetic of one of the fused RQS layer kernels' matrix paths, so that
+ * the GEMM-level error of each path can be measured against an fp64 product (tests/test_gpu_gemm_error.py):
+ * VCNF_PROBE_F32 - v_mfma_f32_16x16x4_f32 chain as in vcnf_rqs_layer_fused_f32(VCNF_PREC_F32);
+ * VCNF_PROBE_F16X3 - split-half operands, hi*hi + (hi*lo + lo*hi) 2^-11 (hidden / last layers of VCNF_PREC_F16X3);
+ * VCNF_PROBE_F16X3_LL - the same plus the lo*lo term (its first layer).  relu_input != 0 applies max(x, 0) to the
+ * input first (the hidden layers see relu(h), resnet.py:42-46).  K % 16 == 0, N % 32 == 0.  sat_count as in
+ * vcnf_rqs_layer_fused_f32 (may be NULL). */
+enum { VCNF_PROBE_F32 = 0, VCNF_PROBE_F16X3 = 1, VCNF_PROBE_F16X3_LL = 2 };
+int vcnf_linear_probe_f32(const float* x, const float* weight, const float* bias, float* y, int64_t batch,
+                          int32_t in_features, int32_t out_features, int mode, int relu_input,
+                          int32_t* sat_count, void* stream);
 
 #ifdef __cplusplus
 }

@@ -708,12 +708,14 @@ def test_fused_path_is_taken_and_matches_split_path(hip):
 
 
 def test_fp16x3_saturation_is_counted_and_fp32_restores_parity(hip):
-    """The split-half matrix path clamps inputs, context and hidden activations at +-65504 (the reference is plain
-    fp32, nets/resnet.py:92-106).  The kernel counts workgroups that clamped; nf.check_saturation() raises, or -
-    given the model - switches the couplings to the exact fp32 matrix path, after which the oracle's result is
-    reproduced.  Hidden weights are scaled up until the counter trips."""
+    """Legacy form of the split-half matrix path (``range_safe = False``: one launch, no fp32 pass behind it): inputs,
+    context and hidden activations are clamped at +-65504 (the reference is plain fp32, nets/resnet.py:92-106).  The
+    kernel counts tiles that clamped; nf.check_saturation() raises, or - given the model - switches the couplings to
+    the exact fp32 matrix path, after which the oracle's result is reproduced.  Hidden weights are scaled up until
+    the counter trips."""
     torch.manual_seed(22)
     m = set_fused(nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8, num_context_channels=16).cuda().eval(), "fp16x3")
+    m.prqct.range_safe = False
     x = torch.randn(512, 64, device="cuda")
     ctx = torch.randn(512, 16, device="cuda")
     nf.check_saturation()                                   # clear
@@ -750,6 +752,61 @@ def test_fp16x3_saturation_is_counted_and_fp32_restores_parity(hip):
     parity(ld32, ldo, ldo64, what="fp32 route log_det")
     # and the clamped run really differs (that is what the counter is for)
     assert float((ld16.cpu() - ldo).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("blocks", [1, 2, 3])
+@pytest.mark.parametrize("sampling", [False, True], ids=["density", "sampling"])
+def test_fp16x3_default_is_range_safe_on_the_device(hip, blocks, sampling):
+    """The DEFAULT matrix path (fp16 split-half operands) never clamps: a 128-sample tile that holds a value the fp16
+    halves cannot carry - a hidden activation beyond +-65504, a huge input, a NaN / Inf input - is left unwritten by the
+    split-half kernel and evaluated by the exact fp32 kernel in the launch behind it, without a host round trip.
+    Asserted: those tiles are BITWISE the exact fp32 path's results (non-finite patterns included), every other tile
+    is BITWISE the split-half path's own result on clean inputs, the redo counter says which is which, and both
+    log_det modes (store / accumulate into a running log_q) honour the skip."""
+    torch.manual_seed(40 + blocks)
+    m = set_fused(nf.flows.CoupledRationalQuadraticSpline(64, blocks, 128, 8, num_context_channels=16).cuda().eval(), "fp16x3")
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "unnormalized_" in n:
+                p.normal_(0.0, 0.5)
+    B = 128 * 5 + 37                                       # six tiles, the last one ragged
+    x = torch.randn(B, 64, device="cuda")
+    ctx = torch.randn(B, 16, device="cuda")
+    call = (lambda mod, a, c: mod.forward(a, context=c)) if sampling else (lambda mod, a, c: mod.inverse(a, context=c))
+    nf.range_redo_count()
+    with torch.no_grad():
+        z_clean, ld_clean = call(m, x, ctx)
+    assert nf.range_redo_count() == 0
+    idf, tff = m.prqct.identity_features.tolist(), m.prqct.transform_features.tolist()
+    xb, cb = x.clone(), ctx.clone()
+    xb[130, idf[3]] = 3.0e5               # tile 1: an identity feature (conditioner input) beyond the fp16 range
+    cb[300, 5] = float("inf")             # tile 2: non-finite context
+    xb[128 * 4 + 7, idf[0]] = float("nan")    # tile 4: NaN conditioner input
+    xb[10, tff[2]] = 1.0e6                # tile 0: a TRANSFORMED feature may be anything (it never enters a GEMM)
+    bad_tiles = [1, 2, 4]
+    with torch.no_grad():
+        z, ld = call(m, xb, cb)
+        assert nf.range_redo_count() == len(bad_tiles)
+        m32 = set_fused(m, "fp32")
+        z32, ld32 = call(m32, xb, cb)
+        set_fused(m, "fp16x3")
+        # accumulate mode: the running log_q of NormalizingFlow.log_prob / sample
+        logq = torch.full((B,), 0.25, device="cuda")
+        z_acc = m.forward_into(xb, logq, context=cb) if sampling else m.inverse_into(xb, logq, context=cb)
+    torch.cuda.synchronize()
+    rows = torch.arange(B, device="cuda") // 128
+    redo = torch.isin(rows, torch.tensor(bad_tiles, device="cuda"))
+    eq = lambda a, b: torch.equal(a, b) or torch.equal(torch.nan_to_num(a, nan=1.25e30), torch.nan_to_num(b, nan=1.25e30))
+    assert eq(z[redo], z32[redo]) and eq(ld[redo], ld32[redo]), "flagged tiles must carry the exact fp32 kernel's results"
+    keep = ~redo
+    keep[10] = False                       # row 10's own transformed input differs from the clean run
+    assert torch.equal(z[keep], z_clean[keep]) and torch.equal(ld[keep], ld_clean[keep])
+    assert torch.equal(z[10, idf], z_clean[10, idf])
+    assert not torch.isfinite(z[300]).all() and not torch.isfinite(z[128 * 4 + 7]).all()      # the reference propagates them
+    sign = -1.0 if sampling else 1.0
+    assert eq(z_acc, z)
+    assert eq(logq, 0.25 + sign * ld)
+    nf.range_redo_count()
 
 
 def test_data_mutation_needs_refresh_packed(hip):

@@ -309,7 +309,7 @@ def test_refresh_packed_invalidates_every_cache():
     import torch
     import vcnf_amd as nf
     lay = nf.flows.CoupledRationalQuadraticSpline(8, 1, 16, 4)
-    lay.prqct.__dict__['_fused_pack'] = (("key",), torch.zeros(3))
+    lay.prqct.__dict__['_fused_pack'] = {0: (("key",), torch.zeros(3)), 1: (("key",), torch.zeros(3))}   # one per matrix path
     lay.prqct.__dict__['_fused_final_pack'] = {'key': 1, 'buf': torch.zeros(2)}
     lu = nf.flows.LULinearPermute(8)
     lu.linear._mats[("k",)] = torch.zeros(1)
@@ -317,13 +317,14 @@ def test_refresh_packed_invalidates_every_cache():
     blk.__dict__['_fused_affine_pack'] = {'key': 2, 'buf': torch.zeros(2)}
     model = nf.NormalizingFlow(nf.distributions.DiagGaussian(8), [lay, lu, blk])
     model.eval()                                            # train(False) runs refresh_packed
-    assert lay.prqct.__dict__['_fused_pack'][0] is None and lay.prqct.__dict__['_fused_pack'][1] is not None
+    for prec in (0, 1):
+        assert lay.prqct.__dict__['_fused_pack'][prec][0] is None and lay.prqct.__dict__['_fused_pack'][prec][1] is not None
     assert lay.prqct.__dict__['_fused_final_pack']['key'] is None
     assert blk.__dict__['_fused_affine_pack']['key'] is None
     assert len(lu.linear._mats) == 0
-    lay.prqct.__dict__['_fused_pack'] = (("key",), torch.zeros(3))
+    lay.prqct.__dict__['_fused_pack'] = {1: (("key",), torch.zeros(3))}
     model.load_state_dict(model.state_dict())
-    assert lay.prqct.__dict__['_fused_pack'][0] is None
+    assert lay.prqct.__dict__['_fused_pack'][1][0] is None
     # caches added in round 2: trunk pack, affine stack buffer + descriptors, memoised stack plans, the GlowBlock's
     # composed mixer, the conditioner's packed 1x1 convolution
     lay.prqct.__dict__['_fused_trunk_pack'] = {'key': 3, 'buf': torch.zeros(2)}

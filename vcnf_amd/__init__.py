@@ -11,7 +11,7 @@ behind the C ABI of ``include/vcnf_hip.h``.  No CPU path: CPU tensors raise.
     with torch.no_grad():
         log_q = model.log_prob(x)
 """
-from ._lib import lib, lib_path, VcnfError, check_discriminant, check_saturation   # noqa: F401
+from ._lib import lib, lib_path, VcnfError, check_discriminant, check_saturation, range_redo_count   # noqa: F401
 from . import utils, nets, flows, distributions                  # noqa: F401
 from .core import NormalizingFlow, MultiscaleFlow                # noqa: F401
 from .sharded import ShardedEvaluator, shard_bounds              # noqa: F401

@@ -81,8 +81,9 @@ PROTOTYPES = {
                                     _P, _P], _INT),
     "vcnf_rqs_layer_fused_pack_floats": ([_I32, _I32, _I32, _I32], _I64),
     "vcnf_rqs_layer_fused_supported": ([_I32, _I32, _I32, _I32, _I32, _I32, _I32], _INT),
+    "vcnf_rqs_layer_fused_tile_rows": ([], _I32),
     "vcnf_rqs_layer_fused_f32": ([_P, _P, _P, _P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _I64,
-                                  _P, _P, _P, ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P, _P], _INT),
+                                  _P, _P, _P, ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P, _P, _P], _INT),
     "vcnf_affine_coupling_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _INT, _INT,
                                   _INT, _F32, _P], _INT),
     "vcnf_resnet_trunk_supported": ([_I32, _I32, _I32], _INT),
@@ -99,6 +100,7 @@ PROTOTYPES = {
     "vcnf_permute_f32": ([_P, _P, _P, _I64, _I32, _I32, _P], _INT),
     "vcnf_diag_gaussian_log_prob_f32": ([_P, _P, _P, _F32, _P, _I64, _I32, _INT, _F32, _P], _INT),
     "vcnf_diag_gaussian_sample_f32": ([_P, _P, _P, _F32, _P, _P, _I64, _I32, _P], _INT),
+    "vcnf_linear_probe_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _INT, _INT, _P, _P], _INT),
 }
 
 _LIB = None
@@ -255,6 +257,24 @@ def saturation_counter(device):
     """Device int32 that the fp16 split-half fused layer kernel bumps (once per workgroup) when an input, a
     context value or a hidden activation was clamped at +-65504."""
     return _counter(_SAT, device)
+
+
+_REDO = {}
+
+
+def range_redo_counter(device):
+    """Device int32: tiles (128 samples) of fused RQS layers that held a value the fp16 split-half operands cannot
+    carry and were therefore evaluated by the exact fp32 kernel instead (never clamped)."""
+    return _counter(_REDO, device)
+
+
+def range_redo_count(device="cuda"):
+    """Host read (synchronises) and reset of ``range_redo_counter``: a statistic, not an error - those tiles have
+    exact fp32 results."""
+    c = range_redo_counter(device)
+    n = int(c.item())
+    c.zero_()
+    return n
 
 
 def check_discriminant(device="cuda"):
@@ -472,10 +492,32 @@ def rqs_conditioner_input(x, id_idx, context, shared, cfg, apply_inverse_shared)
     return out
 
 
+_REDO_FLAGS = {}
+
+
+def _redo_flags(dev, tiles):
+    """Per-tile flag words of the split-half kernel's range check.  One grow-only buffer per (device, stream): the
+    split-half launch writes it and the fp32 launch behind it on the same stream reads it, so consecutive layers can
+    share it.  Under stream capture a fresh buffer is taken from the capturing allocator instead (a HIP graph keeps
+    the address)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(tiles, dtype=torch.int32, device=dev)
+    key = (device_index(dev), torch.cuda.current_stream().cuda_stream)
+    buf = _REDO_FLAGS.get(key)
+    if buf is None or buf.numel() < tiles:
+        buf = torch.empty(max(tiles, 8192), dtype=torch.int32, device=dev)
+        _REDO_FLAGS[key] = buf
+    return buf
+
+
 def rqs_layer_fused(x, context, tf_idx, id_idx, ctx_dim, hidden, num_blocks, precision, wpack, shared, cfg,
-                    inverse, logdet=None, sign=1.0):
-    """Whole coupling layer (conditioner included) in one kernel; see csrc/fused_layer.hip."""
-    dev = require_device(x, context, wpack, logdet, *(shared or ()))
+                    inverse, logdet=None, sign=1.0, wpack_f32=None, cfg_f32=None):
+    """Whole coupling layer (conditioner included) in one kernel; see csrc/fused_layer.hip.
+    precision 1 (fp16 split-half operands) with ``wpack_f32`` given is the range-safe form: the split-half launch
+    leaves tiles that hold a non-finite input or a value beyond +-65504 unwritten and flags them, a launch of the
+    exact fp32 kernel behind it evaluates exactly those tiles (normally none: it returns at once) - no host round
+    trip, nothing clamped.  Without ``wpack_f32`` the split-half kernel clamps and counts (saturation_counter)."""
+    dev = require_device(x, context, wpack, logdet, wpack_f32, *(shared or ()))
     b, d = x.shape
     x = x.contiguous()
     if context is not None:
@@ -487,20 +529,28 @@ def rqs_layer_fused(x, context, tf_idx, id_idx, ctx_dim, hidden, num_blocks, pre
         mode = LD_STORE
     sw, sh, sd = shared if shared is not None else (None, None, None)
     sink = EVENT_SINK
+    L = lib()
+    safe = precision == 1 and wpack_f32 is not None
+
+    def launch(prec, pack, cf, sat, redo):
+        return L.vcnf_rqs_layer_fused_f32(_ptr(x), _ptr(context), _ptr(y), _ptr(logdet), b,
+                                          _ptr(tf_idx), tf_idx.numel(), _ptr(id_idx), id_idx.numel(),
+                                          int(ctx_dim), int(hidden), int(num_blocks), int(prec),
+                                          _ptr(pack), pack.numel(), _ptr(sw), _ptr(sh), _ptr(sd),
+                                          ctypes.byref(cf), int(bool(inverse)), mode, float(sign),
+                                          _ptr(bad_discriminant_counter(dev)) if inverse else None, sat, redo, _stream())
     with torch.cuda.device(dev):
+        flags = _redo_flags(dev, (b + 127) // 128) if safe and b > 0 else None
         if sink is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        st = lib().vcnf_rqs_layer_fused_f32(_ptr(x), _ptr(context), _ptr(y), _ptr(logdet), b,
-                                            _ptr(tf_idx), tf_idx.numel(), _ptr(id_idx), id_idx.numel(),
-                                            int(ctx_dim), int(hidden), int(num_blocks), int(precision),
-                                            _ptr(wpack), wpack.numel(), _ptr(sw), _ptr(sh), _ptr(sd),
-                                            ctypes.byref(cfg), int(bool(inverse)), mode, float(sign),
-                                            _ptr(bad_discriminant_counter(dev)) if inverse else None,
-                                            _ptr(saturation_counter(dev)) if precision == 1 else None, _stream())
+        st = launch(precision, wpack, cfg, _ptr(range_redo_counter(dev) if safe else saturation_counter(dev)) if precision == 1 else None,
+                    _ptr(flags))
         if sink is not None:
             ev1.record()
             sink.append((ev0, ev1, b))
+        if st == OK and flags is not None:
+            st = launch(0, wpack_f32, cfg_f32 if cfg_f32 is not None else cfg, None, _ptr(flags))
     _check(st, "vcnf_rqs_layer_fused_f32")
     return y, logdet
 
@@ -766,13 +816,15 @@ def convnet3_fused(x, w1pack, w2pack, w3pack, b1, b2, b3, c_out, slope1, slope2)
     b, c_in, h, w = x.shape
     z = torch.empty((b, 9 * c_out, h, w), dtype=torch.float32, device=dev)
     out = torch.empty((b, c_out, h, w), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _timed("convnet3_fused"):
-        st = lib().vcnf_convnet3_taps_f16x3_f32(_ptr(x), _ptr(z), _ptr(w1pack), w1pack.numel(), _ptr(w2pack), w2pack.numel(),
-                                                _ptr(w3pack), w3pack.numel(), _ptr(b1), _ptr(b2), b, int(c_in), int(c_out),
-                                                int(h), int(w), float(slope1), float(slope2),
-                                                _ptr(saturation_counter(dev)), _stream())
+    with torch.cuda.device(dev):
+        with _timed("convnet3_taps"):
+            st = lib().vcnf_convnet3_taps_f16x3_f32(_ptr(x), _ptr(z), _ptr(w1pack), w1pack.numel(), _ptr(w2pack), w2pack.numel(),
+                                                    _ptr(w3pack), w3pack.numel(), _ptr(b1), _ptr(b2), b, int(c_in), int(c_out),
+                                                    int(h), int(w), float(slope1), float(slope2),
+                                                    _ptr(saturation_counter(dev)), _stream())
         _check(st, "vcnf_convnet3_taps_f16x3_f32")
-        st = lib().vcnf_col2im3x3_f32(_ptr(z), _ptr(b3), _ptr(out), b, int(c_out), int(h), int(w), _stream())
+        with _timed("col2im3x3"):
+            st = lib().vcnf_col2im3x3_f32(_ptr(z), _ptr(b3), _ptr(out), b, int(c_out), int(h), int(w), _stream())
     _check(st, "vcnf_col2im3x3_f32")
     return out
 
@@ -849,3 +901,22 @@ def diag_gaussian_sample(eps, loc, log_scale, temperature=None):
                                                  b, e2.shape[1], _stream())
     _check(st, "vcnf_diag_gaussian_sample_f32")
     return z.view(eps.shape), logp
+
+
+PROBE_F32, PROBE_F16X3, PROBE_F16X3_LL = 0, 1, 2
+
+
+def linear_probe(x, weight, bias, mode, relu_input=False):
+    """Diagnostic (vcnf_linear_probe_f32): one dense layer evaluated with the arithmetic of one matrix path of the
+    fused RQS layer kernels.  x [B, K], weight [N, K], bias [N] or None -> y [B, N]."""
+    dev = require_device(x, weight, bias)
+    x, weight = x.contiguous(), weight.contiguous()
+    b, k = x.shape
+    n = weight.shape[0]
+    if weight.shape[1] != k or (bias is not None and bias.shape != (n,)):
+        raise VcnfError("linear_probe: shapes %s %s" % (tuple(x.shape), tuple(weight.shape)))
+    y = torch.empty(b, n, device=dev, dtype=torch.float32)
+    _check(lib().vcnf_linear_probe_f32(_ptr(x), _ptr(weight), _ptr(bias.contiguous() if bias is not None else None),
+                                       _ptr(y), b, k, n, int(mode), int(bool(relu_input)),
+                                       _ptr(saturation_counter(dev)), _stream()), "vcnf_linear_probe_f32")
+    return y

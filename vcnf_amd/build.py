@@ -12,14 +12,15 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libvcnf_hip.so")
 SOURCES = ["rqs_kernels.hip", "affine_kernels.hip", "fused_layer.hip",
            "fused_layer_v6.hip", "fused_affine.hip", "fused_final.hip", "resnet_trunk.hip", "channel_mix.hip", "conv1x1.hip", "conv3x3_1x1.hip", "linear_wgrad.hip", "resblock_ops.hip",
-           "rqs_backward.hip"]
+           "rqs_backward.hip", "gemm_probe.hip"]
 # (source, extra flags, object name): fused_layer_v6.hip is compiled once per number of residual blocks.  The two
 # kernels whose spline code runs beside matrix instructions are built without SLP vectorisation: packed-f32 vector
 # instructions starve beside the partner wave's matrix instructions (profiles/r02_spline_eval_microbench.md)
 NO_SLP = ["-fno-slp-vectorize"]
 UNITS = [(s, NO_SLP if s == "fused_final.hip" else [], os.path.splitext(s)[0]) for s in SOURCES if s != "fused_layer_v6.hip"] + \
-        [("fused_layer_v6.hip", ["-DVCNF_V6_NBLK=%d" % n] + NO_SLP, "fused_layer_v6_b%d" % n) for n in (2, 3, 1)]
-HEADERS = ["rqs_math.hpp", "rqs_lean.hpp", "fused_common.hpp", os.path.join("..", "..", "include", "vcnf_hip.h")]
+        [("fused_layer_v6.hip", ["-DVCNF_V6_NBLK=%d" % n] + NO_SLP, "fused_layer_v6_b%d" % n) for n in (2, 3, 1)] + \
+        [("fused_layer.hip", ["-DVCNF_F32_NBLK=%d" % n], "fused_layer_f32_b%d" % n) for n in (3, 1)]
+HEADERS = ["rqs_math.hpp", "rqs_lean.hpp", "fused_common.hpp", "split_half.hpp", os.path.join("..", "..", "include", "vcnf_hip.h")]
 
 
 def stale():

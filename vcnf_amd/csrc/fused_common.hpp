@@ -11,6 +11,7 @@ namespace vcnf {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int kFBlock = 256;     // 4 waves; each wave owns kCB 16-sample column blocks of the tile
+constexpr int kFusedTile = 128;  // samples per tile of BOTH fused layer kernels (the redo flags are per tile)
 
 struct FusedArgs {
   const float* x;
@@ -23,7 +24,10 @@ struct FusedArgs {
   const float* wpack;                    // packed conditioner weights, layout below
   unsigned wpack_bytes;
   int32_t* bad;
-  int32_t* sat;                          // fp16 split-half path: workgroups that clamped a value at +-65504 (or NULL)
+  int32_t* sat;                          // fp16 split-half path: tiles with a value beyond the fp16 range (or NULL)
+  int32_t* redo;                         // [tiles of kFusedTile rows] or NULL.  Split-half kernel: OUT - 1 for a tile that
+                                         // held a non-finite input or a value beyond +-65504 (nothing of that tile is
+                                         // written), else 0.  Exact fp32 kernel: IN - only flagged tiles are evaluated.
   long long B;
   int ld_mode;
   float ld_sign;
@@ -136,6 +140,10 @@ struct PackLayout6 {
   static constexpr int TOTAL = BF + NG * 96;
   static_assert(TOTAL == PackLayout<DI, DT, C, H, NBLK, K>::TOTAL, "both matrix paths take a buffer of the same size");
 };
+
+// defined in fused_layer.hip built with -DVCNF_F32_NBLK=1 / 3 (exact fp32 kernel, one / three residual blocks)
+int launch_fused_f32_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
+int launch_fused_f32_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
 
 // defined in fused_layer_v6.hip
 int launch_fused_v6_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);

@@ -64,6 +64,7 @@ __device__ __forceinline__ void bias_block(__amdgpu_buffer_rsrc_t rsrc, int qoff
 template <int DI, int DT, int C, int H, int NBLK, int K, bool INV, int kCB>
 __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const FusedArgs a) {
   constexpr int kTile = 4 * kCB * 16;       // samples per workgroup tile
+  static_assert(kTile == kFusedTile, "the redo flags of the split-half kernel are per 128-sample tile");
   constexpr int D = DI + DT;
   constexpr int XS = D + 4;                 // padded LDS row strides (16-byte aligned rows)
   constexpr int CS = (C > 0 ? C : 4) + 4;
@@ -104,6 +105,8 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
   const long long ntiles = (a.B + kTile - 1) / kTile;
   bool bad = false;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // re-evaluation pass behind the split-half kernel: only the tiles it flagged (and did not write)
+    if (a.redo && a.redo[tile] == 0) continue;
     const long long b0 = tile * kTile;
     const int rows = (int)min((long long)kTile, a.B - b0);
     __syncthreads();
@@ -298,12 +301,35 @@ static int launch_fused(const FusedArgs& a, int inverse, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }
 
+// Shape family of the exact fp32 kernel: (d_id = d_t, ctx) with H = 128, 8 bins, NBLK residual blocks.
+template <int NBLK>
+static int launch_fused_f32_family(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+  if (d_id == 32)
+    return ctx_dim == 16 ? launch_fused<32, 32, 16, 128, NBLK, 8, 2>(a, inverse, st)
+                         : launch_fused<32, 32, 0, 128, NBLK, 8, 2>(a, inverse, st);
+  return ctx_dim == 16 ? launch_fused<16, 16, 16, 128, NBLK, 8, 2>(a, inverse, st)
+                       : launch_fused<16, 16, 0, 128, NBLK, 8, 2>(a, inverse, st);
+}
+
+// One- and three-block layers are compiled as their own translation units (-DVCNF_F32_NBLK=1|3, build.py runs
+// them in parallel); the unit without the macro holds the two-block kernels and the C entry points.
+#if defined(VCNF_F32_NBLK) && VCNF_F32_NBLK == 1
+int launch_fused_f32_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+  return launch_fused_f32_family<1>(a, d_id, ctx_dim, inverse, st);
+}
+#elif defined(VCNF_F32_NBLK) && VCNF_F32_NBLK == 3
+int launch_fused_f32_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+  return launch_fused_f32_family<3>(a, d_id, ctx_dim, inverse, st);
+}
+#endif
+
 }  // namespace vcnf
 
+#ifndef VCNF_F32_NBLK
 using namespace vcnf;
 
 // shape family: d_id = d_t in {16, 32}, context 0 or 16, 1-3 residual blocks (hidden 128, 8 bins, linear
-// tails).  Two blocks run on both matrix paths; one and three blocks on the fp16 split-half path only.
+// tails), on both matrix paths.
 template <int NBLK>
 static int64_t pack_total(int d_id, int ctx_dim) {
   if (d_id == 32) return ctx_dim == 16 ? PackLayout<32, 32, 16, 128, NBLK, 8>::TOTAL : PackLayout<32, 32, 0, 128, NBLK, 8>::TOTAL;
@@ -319,6 +345,8 @@ extern "C" int64_t vcnf_rqs_layer_fused_pack_floats(int32_t d_id, int32_t d_t, i
     default: return 0;
   }
 }
+
+extern "C" int32_t vcnf_rqs_layer_fused_tile_rows(void) { return kFusedTile; }
 
 extern "C" int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t ctx_dim, int32_t hidden,
                                               int32_t num_blocks, int32_t num_bins, int32_t tails) {
@@ -342,7 +370,8 @@ extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, fl
                                         const float* wpack, int64_t wpack_floats,
                                         const float* shared_w, const float* shared_h, const float* shared_d,
                                         const vcnf_rqs_cfg* cfg, int inverse,
-                                        int ld_mode, float ld_sign, int32_t* bad_disc, int32_t* sat_count, void* stream) {
+                                        int ld_mode, float ld_sign, int32_t* bad_disc, int32_t* sat_count,
+                                        int32_t* redo_tiles, void* stream) {
   if (!cfg || !wpack) return VCNF_ERR_NULL;
   if (!vcnf_rqs_layer_fused_supported(d_id, d_t, ctx_dim, hidden, num_blocks, cfg->num_bins, cfg->tails))
     return VCNF_ERR_UNSUPPORTED;
@@ -363,7 +392,7 @@ extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, fl
   a.tf_idx = transform_idx; a.id_idx = identity_idx;
   a.sh_w = shared_w; a.sh_h = shared_h; a.sh_d = shared_d;
   a.wpack = wpack; a.wpack_bytes = (unsigned)(wpack_floats * 4);
-  a.bad = bad_disc; a.sat = sat_count; a.B = batch; a.ld_mode = ld_mode; a.ld_sign = ld_sign;
+  a.bad = bad_disc; a.sat = sat_count; a.redo = redo_tiles; a.B = batch; a.ld_mode = ld_mode; a.ld_sign = ld_sign;
   const int K = cfg->num_bins;
   a.c.K = K; a.c.tails = cfg->tails;
   a.c.lo_x = cfg->left; a.c.hi_x = cfg->right; a.c.span_x = (float)((double)cfg->right - (double)cfg->left);
@@ -376,10 +405,8 @@ extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, fl
   hipStream_t st = (hipStream_t)stream;
   if (wpack_floats != vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim, num_blocks)) return VCNF_ERR_SHAPE;
   if (precision == VCNF_PREC_F16X3) return launch_f16x3(a, d_id, ctx_dim, num_blocks, inverse, st);
-  if (num_blocks != 2) return VCNF_ERR_UNSUPPORTED;      // exact fp32 matrix path: two-block layers only
-  if (d_id == 32)
-    return ctx_dim == 16 ? launch_fused<32, 32, 16, 128, 2, 8, 2>(a, inverse, st)
-                         : launch_fused<32, 32, 0, 128, 2, 8, 2>(a, inverse, st);
-  return ctx_dim == 16 ? launch_fused<16, 16, 16, 128, 2, 8, 2>(a, inverse, st)
-                       : launch_fused<16, 16, 0, 128, 2, 8, 2>(a, inverse, st);
+  if (num_blocks == 1) return launch_fused_f32_b1(a, d_id, ctx_dim, inverse, st);
+  if (num_blocks == 3) return launch_fused_f32_b3(a, d_id, ctx_dim, inverse, st);
+  return launch_fused_f32_family<2>(a, d_id, ctx_dim, inverse, st);
 }
+#endif  // VCNF_F32_NBLK

@@ -44,6 +44,7 @@
 #include "rqs_math.hpp"
 #include "fused_common.hpp"
 #include "rqs_lean.hpp"
+#include "split_half.hpp"
 
 #ifndef VCNF_ABL
 #define VCNF_ABL 0
@@ -74,36 +75,6 @@
 #define VCNF_SYNC() { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 
 namespace vcnf {
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef float float2v __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ floatx16 mfma32h(half8 a, half8 b, floatx16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
-// hi / lo halves of eight values; the running maximum of what was clamped goes to ``satm``
-template <bool RELU>
-__device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo, float& satm) {
-#pragma unroll
-  for (int i = 0; i < 8; i += 2)
-    satm = RELU ? fmaxf(fmaxf(satm, v[i]), v[i + 1]) : fmaxf(fmaxf(satm, __builtin_fabsf(v[i])), __builtin_fabsf(v[i + 1]));
-  // pin the running maximum here: left alone the compiler sinks these updates to the end of the tile and keeps
-  // (spills) every value that ever went through a split until then
-  asm volatile("" : "+v"(satm));
-#pragma unroll
-  for (int i = 0; i < 8; i += 2) {
-    const float x0 = __builtin_amdgcn_fmed3f(v[i], RELU ? 0.f : -65504.f, 65504.f);
-    const float x1 = __builtin_amdgcn_fmed3f(v[i + 1], RELU ? 0.f : -65504.f, 65504.f);
-    const half2v h2 = __builtin_convertvector(float2v{x0, x1}, half2v);
-    hi[i] = h2[0];
-    hi[i + 1] = h2[1];
-    lo[i] = (_Float16)__builtin_fmaf((float)h2[0], -kLoScale, x0 * kLoScale);
-    lo[i + 1] = (_Float16)__builtin_fmaf((float)h2[1], -kLoScale, x1 * kLoScale);
-  }
-}
-
 
 template <int DI, int DT, int C, int H, int NBLK, int K, bool INV>
 __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6_kernel(const FusedArgs a) {
@@ -140,6 +111,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6_kernel(const FusedA
   int* tfi = reinterpret_cast<int*>(ldt + kTile);
   int* idi = tfi + DT;
   float* biasf = reinterpret_cast<float*>(idi + DI + 4);   // [NG][lane half][48] last-layer bias (3 KB)
+  int* tflag = reinterpret_cast<int*>(biasf + NG * 96);    // this tile held a value the fp16 halves cannot carry
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -200,9 +172,11 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6_kernel(const FusedA
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long b0 = tile * kTile;
     const int rows = (int)min((long long)kTile, a.B - b0);
+    satm = 0.f;
     { VCNF_T(0) VCNF_SYNC(); VCNF_T(15) }
     {   // ---- x rows -> LDS tile; context row quarter -> half of a B fragment (hi | lo)
       constexpr int D4 = D / 4;
+      if (tid == 0) *tflag = 0;
 #pragma unroll
       for (int k = 0; k < kTile * D4 / kBlock; ++k) {
         const int i = tid + kBlock * k;
@@ -214,8 +188,9 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6_kernel(const FusedA
         const int r = tid >> 2, part = tid & 3;
         half4 h4, l4;
         const float cv[4] = {cpre[0].x, cpre[0].y, cpre[0].z, cpre[0].w};
-        satm = fmaxf(fmaxf(satm, __builtin_fabsf(cv[0])), __builtin_fabsf(cv[1]));
-        satm = fmaxf(fmaxf(satm, __builtin_fabsf(cv[2])), __builtin_fabsf(cv[3]));
+        // raw inputs: a NaN counts as out of range too (fmaxf drops NaNs; the reference propagates them)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) satm = fmaxf(satm, cv[i] == cv[i] ? __builtin_fabsf(cv[i]) : __builtin_inff());
         asm volatile("" : "+v"(satm));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -271,6 +246,9 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6_kernel(const FusedA
       lsum += __shfl_xor(lsum, 1, 64);
       lsum += __shfl_xor(lsum, 2, 64);
       if (part == 0) ldt[mi] = lsum;
+      // raw inputs of the conditioner: NaN / Inf count as out of range (fmaxf in the splits drops NaNs)
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) satm = fmaxf(satm, fv[k] == fv[k] ? 0.f : __builtin_inff());
       // fragment: first-layer k = 16 t + 8 kg' + i  <->  identity feature part * UNR + k
       const int k0 = part * UNR;                               // first feature of this thread
       const int t0 = k0 >> 4, kg0 = (k0 >> 3) & 1;
@@ -429,12 +407,15 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6_kernel(const FusedA
         for (int j = 0; j < 2; ++j) {
           const half8 bh = __builtin_bit_cast(half8, ctxf[((2 * ch + j) * 2 + 0) * 64 + lane]);
           const half8 bl = __builtin_bit_cast(half8, ctxf[((2 * ch + j) * 2 + 1) * 64 + lane]);
-          floatx16 corr = {};
+          // 16-deep layer: the accumulator rounds once, so the operands' 22 bits are what is left of the error -
+          // the lo*lo term is kept like in the first layer (tests/test_gpu_gemm_error.py)
+          floatx16 corr = {}, corr2 = {};
           gate[j] = mfma32h(wch, bh, gbias);
           corr = mfma32h(wch, bl, corr);
           corr = mfma32h(wcl, bh, corr);
+          corr2 = mfma32h(wcl, bl, corr2);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) gate[j][r] = fmaf(corr[r], kLoUnscale, gate[j][r]);
+          for (int r = 0; r < 16; ++r) gate[j][r] = fmaf(fmaf(corr2[r], kLoUnscale, corr[r]), kLoUnscale, gate[j][r]);
         }
       }
       { VCNF_T(5) VCNF_SYNC(); VCNF_T(15) }
@@ -587,7 +568,17 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6_kernel(const FusedA
     // wave (other parity) adds its share through LDS (ldt already holds the identity half)
     ld_acc += __shfl_xor(ld_acc, 32, 64);
     if (ch == 1 && kg == 0) ldt[rp * 32 + c32] += ld_acc;
+    if (satm > 65504.f) *tflag = 1;
     { VCNF_T(12) VCNF_SYNC(); VCNF_T(15) }
+    // A tile that held a non-finite input or a value beyond the fp16 range is not written at all when the caller
+    // gave a flag array: the exact fp32 kernel evaluates it from the untouched inputs (vcnf_rqs_layer_fused_f32,
+    // redo_tiles).  Without the array the clamped results are stored and only counted (sat).
+    const bool over = *tflag != 0;
+    if (tid == 0) {
+      if (a.redo) a.redo[tile] = over ? 1 : 0;
+      if (over && a.sat) atomicAdd(a.sat, 1);
+    }
+    if (over && a.redo) continue;
     if (ch == 0 && kg == 0) {
       const int mrow = rp * 32 + c32;
       if (mrow < rows) {
@@ -613,7 +604,6 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6_kernel(const FusedA
   }
 #endif
   if (INV && a.bad && bad) atomicAdd(a.bad, 1);
-  if (a.sat && satm > 65504.f) atomicAdd(a.sat, 1);
 }
 
 template <int DI, int DT, int C, int H, int NBLK, int K>

@@ -69,7 +69,12 @@ def _pack_final(weight, bias, d_t, p):
 
 PREC_F32, PREC_F16X3 = 0, 1
 LO_SCALE = 2048.0
-# matrix path used when a coupling does not set ``fused_precision`` itself
+# Matrix path used when a module does not set ``fused_precision`` itself.  'fp16x3' (fp16 split-half operands, fp32
+# accumulation) is the default because (a) GEMM by GEMM its error against an fp64 product is at or below the exact
+# fp32 matrix path's on every layer shape (tests/test_gpu_gemm_error.py) and (b) the fused RQS layer is range-safe
+# on the device: what the fp16 halves cannot carry is evaluated by the exact fp32 kernel, never clamped (run()).
+# VCNF_FUSED_PRECISION=fp32 / ``fused_precision = 'fp32'`` select exact fp32 matrix instructions everywhere
+# (also for the Glow conv conditioner, whose split-half kernels clamp and count instead: nf.check_saturation()).
 DEFAULT_PRECISION = os.environ.get('VCNF_FUSED_PRECISION', 'fp16x3')
 
 
@@ -199,8 +204,6 @@ def eligible(coupling, context):
         return False
     if context is not None and (context.dim() != 2 or context.shape[1] != ctx_dim):
         return False
-    if len(blocks) != 2 and precision_of(coupling) != PREC_F16X3:
-        return False                                    # the exact fp32 matrix path covers two-block layers only
     return bool(_lib.lib().vcnf_rqs_layer_fused_supported(
         coupling.num_identity_features, coupling.num_transform_features, ctx_dim,
         net.hidden_features, len(blocks), coupling.num_bins, _lib.TAILS_LINEAR))
@@ -213,14 +216,15 @@ def precision_of(coupling):
     return PREC_F16X3 if mode == 'fp16x3' else PREC_F32
 
 
-def packed_weights(coupling):
-    """Cached packed buffer; refreshed when any conditioner parameter (or the matrix precision)
-    changed.  A refresh of the same size rewrites the existing device buffer in place, so a
-    captured HIP graph that holds its address (vcnf_amd.graphs) sees the new weights."""
+def packed_weights(coupling, prec=None):
+    """Cached packed buffer of one matrix path; refreshed when any conditioner parameter changed.  A refresh of the
+    same size rewrites the existing device buffer in place, so a captured HIP graph that holds its address
+    (vcnf_amd.graphs) sees the new weights."""
     net = coupling.transform_net
-    prec = precision_of(coupling)
-    key = (prec,) + tuple((p.data_ptr(), p._version) for p in net.parameters())
-    cache = coupling.__dict__.get('_fused_pack')
+    prec = precision_of(coupling) if prec is None else prec
+    key = tuple((p.data_ptr(), p._version) for p in net.parameters())
+    packs = coupling.__dict__.setdefault('_fused_pack', {})
+    cache = packs.get(prec)
     if cache is None or cache[0] != key:
         with torch.no_grad():
             if prec == PREC_F16X3:
@@ -232,17 +236,24 @@ def packed_weights(coupling):
                 cache[1].copy_(buf)
                 buf = cache[1]
         cache = (key, buf)
-        coupling.__dict__['_fused_pack'] = cache
+        packs[prec] = cache
     return cache[1]
 
 
 def run(coupling, inputs, context, sampling, log_q=None, sign=1.0):
+    """One launch of the fused layer kernel on the coupling's matrix path.  'fp16x3' is range-safe: tiles holding a
+    non-finite input or a value beyond the fp16 range are evaluated by the exact fp32 kernel in a second launch that
+    otherwise returns at once (_lib.rqs_layer_fused); ``coupling.range_safe = False`` drops that launch (the
+    split-half kernel then clamps at +-65504 and counts, nf.check_saturation())."""
     net = coupling.transform_net
     shared = coupling.unconditional_transform.logits() if coupling.unconditional_transform is not None else None
+    prec = precision_of(coupling)
+    safe = prec == PREC_F16X3 and getattr(coupling, 'range_safe', True)
     return _lib.rqs_layer_fused(inputs, context, coupling._index32('tf'), coupling._index32('id'),
                                 net.context_features or 0, net.hidden_features, len(net.blocks),
-                                precision_of(coupling), packed_weights(coupling), shared, coupling._cfg(True), sampling,
-                                logdet=log_q, sign=sign)
+                                prec, packed_weights(coupling, prec), shared, coupling._cfg(True), sampling,
+                                logdet=log_q, sign=sign,
+                                wpack_f32=packed_weights(coupling, PREC_F32) if safe else None)
 
 
 def refresh_packed(module):
@@ -254,8 +265,9 @@ def refresh_packed(module):
     Buffers are rewritten in place at the next use, so a captured HIP graph keeps its addresses."""
     for m in module.modules():
         d = m.__dict__
-        if d.get('_fused_pack') is not None:
-            d['_fused_pack'] = (None, d['_fused_pack'][1])
+        if isinstance(d.get('_fused_pack'), dict):
+            for prec, (key, buf) in list(d['_fused_pack'].items()):
+                d['_fused_pack'][prec] = (None, buf)
         for name in ('_fused_affine_pack', '_fused_affine_stack', '_fused_final_pack', '_fused_trunk_pack', '_fused_conv_pack',
                      '_fused_conv3_pack', '_fused_taps_pack'):
             if isinstance(d.get(name), dict):

@@ -31,6 +31,9 @@ class ConvNet2d(nn.Module):
 
     # ------------------------------------------------------------------ inference: fused middle layer
     fused_conv1x1 = True
+    # 'fp16x3': the fused kernels' split-half matrix arithmetic; 'fp32': the library's fp32 convolutions (the
+    # reference's arithmetic, nets/cnn.py:20-46); None: vcnf_amd.fused.DEFAULT_PRECISION (VCNF_FUSED_PRECISION)
+    fused_precision = None
 
     def _fusable(self, x):
         """Conv(k) , LeakyReLU, Conv(1x1), LeakyReLU, Conv(k) on a CUDA fp32 batch without autograd: the 1x1 convolution
@@ -39,6 +42,9 @@ class ConvNet2d(nn.Module):
         mods = list(self.net)
         if not (self.fused_conv1x1 and len(mods) == 5 and x.dim() == 4 and x.is_cuda and x.dtype == torch.float32):
             return False
+        from .. import fused
+        if fused.precision_of(self) != fused.PREC_F16X3:
+            return False                   # fp32 asked for: every convolution stays on the library's fp32 path
         c1, a1, c2, a2, c3 = mods
         if not (isinstance(c1, nn.Conv2d) and isinstance(c2, nn.Conv2d) and isinstance(c3, nn.Conv2d)
                 and isinstance(a1, nn.LeakyReLU) and isinstance(a2, nn.LeakyReLU)):

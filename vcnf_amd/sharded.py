@@ -37,7 +37,7 @@ def bench_shard(batch, scaling, rank, world_size):
 def max_over_ranks(seconds, device, group=None):
     """Whole-job duration of a timed region: the slowest rank's (one all-reduce MAX of an fp64 scalar)."""
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():      # also with ONE rank: the collective path is the same code
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
@@ -88,8 +88,9 @@ class ShardedEvaluator:
         stats = torch.empty(2, dtype=torch.float64, device=log_q.device)
         stats[0] = log_q.sum(dtype=torch.float64)
         stats[1] = float(log_q.numel())
-        w, _ = self._world()
-        if w > 1:
+        if dist.is_available() and dist.is_initialized():
+            # issued for every world size, 1 included: a single-rank launch (torchrun --nproc-per-node 1) runs the
+            # same RCCL call as N ranks, so the collective path is exercised on a one-GPU box too
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
         return stats
 
