@@ -10,7 +10,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-template <int NV, int TRANS, int THREADS>
+template <int NV, int TRANS, int THREADS, int CH = 8>
 __global__ __launch_bounds__(THREADS) void k(float* out, long long* cyc, int iters) {
   half8 a, b;
   for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(0.5f + i * 0.01f); }
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(THREADS) void k(float* out, long long* cyc, int ite
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         if (TRANS && i == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(v[(u + i) & 7]));
-        else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[(u * NV + i) & 7]) : "v"(k1), "v"(k2));
+        else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[(u * NV + i) % CH]) : "v"(k1), "v"(k2));
       }
     }
   }
@@ -38,16 +38,16 @@ __global__ __launch_bounds__(THREADS) void k(float* out, long long* cyc, int ite
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
-template <int NV, int TRANS, int THREADS>
+template <int NV, int TRANS, int THREADS, int CH = 8>
 void run() {
   float* out; long long* cyc;
   const int iters = 4000, W = THREADS / 64;
   hipMalloc(&out, 256 * THREADS * 4); hipMalloc(&cyc, 256 * W * 8);
-  k<NV, TRANS, THREADS><<<256, THREADS>>>(out, cyc, iters);
+  k<NV, TRANS, THREADS, CH><<<256, THREADS>>>(out, cyc, iters);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  k<NV, TRANS, THREADS><<<256, THREADS>>>(out, cyc, iters);
+  k<NV, TRANS, THREADS, CH><<<256, THREADS>>>(out, cyc, iters);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms = 0.f;
@@ -57,16 +57,20 @@ void run() {
   double m = 0;
   for (int i = 0; i < 256 * W; ++i) m += h[i];
   const double flop = 256.0 * W * iters * 8 * 32768.0;
-  printf("waves/SIMD %d  VALU per MFMA %2d (%s): %7.1f cycles per (MFMA + VALU group) and wave; wall %.3f ms = %.0f TFLOP/s of f16 MFMA, clock %.2f GHz\n", W / 4, NV,
+  printf("chains %d  waves/SIMD %d  VALU per MFMA %2d (%s): %7.1f cycles per (MFMA + VALU group) and wave; wall %.3f ms = %.0f TFLOP/s of f16 MFMA, clock %.2f GHz\n", CH, W / 4, NV,
          TRANS ? "first one v_exp_f32" : "all v_fma_f32", m / (256.0 * W) / iters / 8, ms, flop / ms * 1e-9,
          m / (256.0 * W) / (ms * 1e6));
   hipFree(out); hipFree(cyc);
 }
 
 int main() {
-  run<0, 0, 512>(); run<2, 0, 512>(); run<4, 0, 512>(); run<6, 0, 512>(); run<8, 0, 512>(); run<10, 0, 512>(); run<12, 0, 512>(); run<16, 0, 512>();
+  // dependent chains: the same 6 (or 8) vector instructions per MFMA as 1, 2, 4 or 8 independent chains
+  run<6, 0, 256, 1>(); run<6, 0, 256, 2>(); run<6, 0, 256, 3>(); run<6, 0, 256, 4>(); run<6, 0, 256, 8>();
+  run<8, 0, 256, 1>(); run<8, 0, 256, 2>(); run<8, 0, 256, 4>(); run<8, 0, 256, 8>();
+  run<6, 0, 512, 1>(); run<6, 0, 512, 2>(); run<6, 0, 512, 4>(); run<6, 0, 512, 8>();
+  run<8, 0, 512, 1>(); run<8, 0, 512, 2>(); run<8, 0, 512, 8>();
+  run<0, 0, 512>(); run<4, 0, 512>(); run<8, 0, 512>(); run<12, 0, 512>(); run<16, 0, 512>();
   run<4, 1, 512>(); run<8, 1, 512>(); run<12, 1, 512>();
-  run<0, 0, 1024>(); run<4, 0, 1024>(); run<8, 0, 1024>();
-  run<0, 0, 256>(); run<2, 0, 256>(); run<4, 0, 256>(); run<6, 0, 256>(); run<8, 0, 256>();
+  run<0, 0, 256>(); run<4, 0, 256>(); run<6, 0, 256>(); run<8, 0, 256>();
   return 0;
 }

@@ -776,6 +776,113 @@ def g22_maf():
     save("g22_maf", **out)
 
 
+# ---------------------------------------------------------------- G23: gradients (training path, core.py:33-101)
+def g23_gradients():
+    """Reference autograd through the hot path, fp32 and fp64: for each case a scalar loss, its
+    gradient with respect to the input(s) and to two to four named parameters.  Cases: one RQS coupling layer (G3's module, both
+    directions), the C3 stack at B = 64 (loss = sum log_prob, and the sampling direction's sum log_q + <g, z>), one
+    AffineCouplingBlock (G6: d = 32, exp scale map, channel split) and one MaskedAffineFlow (G7: d = 9, s and t nets).
+    Weights are synthesised as in the forward fixtures; the stored ``gz`` are the fixed cotangents of z."""
+    out = {}
+
+    def grads(build, seed, inputs, loss_fn, names, **gains):
+        """-> per dtype: loss value, d loss / d inputs, d loss / d named parameters"""
+        res = {}
+        ents = None
+        for dt, tag in ((torch.float32, "32"), (torch.float64, "64")):
+            m = build()
+            ents = synth.load_synth(m, seed, **gains)
+            ints = synth.int_buffers(m)
+            if dt == torch.float64:
+                m = m.double()
+            xs = [t.clone().to(dt).requires_grad_() for t in inputs]
+            with torch.enable_grad():
+                loss = loss_fn(m, *xs)
+                ps = dict(m.named_parameters())
+                g = torch.autograd.grad(loss, xs + [ps[n] for n in names])
+            res[tag] = (loss.detach(), [t.detach() for t in g[:len(xs)]], [t.detach() for t in g[len(xs):]])
+        return ents, ints, res
+
+    def store(tag, ents, ints, res, names, n_in):
+        out[tag + "/entries"] = synth.encode_entries(ents)
+        for k, v in ints.items():
+            out[tag + "/int/" + k] = npy(v)
+        out[tag + "/names"] = np.array(names)
+        for prec, (loss, gin, gpar) in res.items():
+            out[tag + "/loss" + prec] = npy(loss)
+            for i in range(n_in):
+                out[tag + "/gin%d_%s" % (i, prec)] = npy(gin[i])
+            for n, gp in zip(names, gpar):
+                out[tag + "/gpar/%s/%s" % (n, prec)] = npy(gp)
+
+    # (a) one RQS coupling layer, both directions
+    r = rng(2300)
+    x = torch.from_numpy((1.2 * r.standard_normal((64, 64))).astype(np.float32))
+    gz = torch.from_numpy(r.standard_normal((64, 64)).astype(np.float32))
+    out["layer/x"], out["layer/gz"] = npy(x), npy(gz)
+    names = ["prqct.transform_net.blocks.1.linear_layers.1.weight", "prqct.transform_net.final_layer.bias",
+             "prqct.unconditional_transform.unnormalized_widths"]
+    for direction in ("inverse", "forward"):
+        def loss_fn(m, a):
+            z, ld = getattr(m, direction)(a)
+            return ld.sum() + (z * gz.to(z.dtype)).sum()
+        ents, ints, res = grads(lambda: nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8), 2301, [x], loss_fn, names,
+                                final_gain=2.0)
+        store("layer/" + direction, ents, ints, res, names, 1)
+
+    # (b) C3 stack, B = 64
+    r = rng(2310)
+    x = torch.from_numpy(r.standard_normal((64, 64)).astype(np.float32))
+    ctx = torch.from_numpy(r.standard_normal((64, 16)).astype(np.float32))
+    eps = torch.from_numpy(r.standard_normal((64, 64)).astype(np.float32))
+    gz = torch.from_numpy(r.standard_normal((64, 64)).astype(np.float32))
+    out["c3/x"], out["c3/ctx"], out["c3/eps"], out["c3/gz"] = npy(x), npy(ctx), npy(eps), npy(gz)
+    names = ["flows.0.prqct.transform_net.final_layer.bias", "flows.11.prqct.transform_net.initial_layer.weight",
+             "flows.5.prqct.transform_net.blocks.0.context_layer.weight", "q0.log_scale"]
+    ents, ints, res = grads(C3Stack, 2311, [x, ctx], lambda m, a, c: m.log_prob(a, c)[1].sum(), names, final_gain=1.0)
+    store("c3/log_prob", ents, ints, res, names, 2)
+
+    def sample_loss(m, e, c):
+        z, lq, _ = m.sample(e, c)
+        return lq.sum() + (z * gz.to(z.dtype)).sum()
+    ents, ints, res = grads(C3Stack, 2311, [eps, ctx], sample_loss, names, final_gain=1.0)
+    store("c3/sample", ents, ints, res, names, 2)
+
+    # (c) one AffineCouplingBlock (d = 32, exp, channel split), both directions
+    r = rng(2320)
+    x = torch.from_numpy(r.standard_normal((128, 32)).astype(np.float32))
+    gz = torch.from_numpy(r.standard_normal((128, 32)).astype(np.float32))
+    out["affine/x"], out["affine/gz"] = npy(x), npy(gz)
+    build = lambda: nf.flows.AffineCouplingBlock(nf.nets.MLP([16, 24, 24, 32], init_zeros=False), scale=True,
+                                                 scale_map="exp", split_mode="channel")
+    names = ["flows.1.param_map.net.0.weight", "flows.1.param_map.net.4.bias"]
+    for direction in ("forward", "inverse"):
+        def loss_fn(m, a):
+            z, ld = getattr(m, direction)(a)
+            return ld.sum() + (z * gz.to(z.dtype)).sum()
+        ents, ints, res = grads(build, 2321, [x], loss_fn, names)
+        store("affine/" + direction, ents, ints, res, names, 1)
+
+    # (d) MaskedAffineFlow d = 9 with s and t nets, both directions
+    r = rng(2330)
+    d = 9
+    x = torch.from_numpy(r.standard_normal((128, d)).astype(np.float32))
+    gz = torch.from_numpy(r.standard_normal((128, d)).astype(np.float32))
+    bmask = torch.tensor([1.0 if i % 2 == 0 else 0.0 for i in range(d)])
+    out["masked/x"], out["masked/gz"], out["masked/b"] = npy(x), npy(gz), npy(bmask)
+    build = lambda: nf.flows.MaskedAffineFlow(bmask.clone(), nf.nets.MLP([d, 16, d], init_zeros=False),
+                                              nf.nets.MLP([d, 16, d], init_zeros=False))
+    names = ["s.net.0.weight", "t.net.2.bias"]
+    for direction in ("forward", "inverse"):
+        def loss_fn(m, a):
+            z, ld = getattr(m, direction)(a)
+            return ld.sum() + (z * gz.to(z.dtype)).sum()
+        ents, ints, res = grads(build, 2331, [x], loss_fn, names, skip=("b",))
+        store("masked/" + direction, ents, ints, res, names, 1)
+    save("g23_gradients", **out)
+
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                            # only the named cases: make_golden.py g20_c4_real_shape ...
         for name_ in sys.argv[1:]:
@@ -803,3 +910,4 @@ if __name__ == "__main__":
     g20_c4_real_shape()
     g21_c5_real_depth()
     g22_maf()
+    g23_gradients()

@@ -240,3 +240,49 @@ def anchored(build_err, oracle_err, what, k_mean=2.0, k_max=4.0, floor=1e-6):
         what, float(b.mean()), float(o.mean()), k_mean)
     assert float(b.max()) <= k_max * float(o.max()) + floor, "%s max %.3e vs oracle %.3e (x%g)" % (
         what, float(b.max()), float(o.max()), k_max)
+
+
+# ---------------------------------------------------------------- gradient fixtures (G23)
+def g23_cases():
+    """The cases of tests/golden/g23_gradients.npz as (tag, seed, gains, input names, cotangent name, make_oracle, call):
+    ``make_oracle(sd)`` builds the oracle object from a (leaf) state dict, ``call(obj, *inputs, gz)`` returns the scalar
+    loss the reference differentiated (tests/golden/make_golden.py::g23_gradients)."""
+    def layer(direction):
+        def loss(o, x, gz):
+            z, ld = getattr(o, direction)(x, None)
+            return ld.reshape(-1).sum() + (z * gz).sum()
+        return loss
+
+    def plain(direction):
+        def loss(o, x, gz):
+            z, ld = getattr(o, direction)(x)
+            return ld.reshape(-1).sum() + (z * gz).sum()
+        return loss
+    cases = []
+    for d in ("inverse", "forward"):
+        cases.append(("layer/" + d, 2301, dict(final_gain=2.0), ["layer/x"], "layer/gz",
+                      lambda sd: oracle_rqs_coupling(sd, "prqct.", 8, 3.0, 128), layer(d)))
+    cases.append(("c3/log_prob", 2311, dict(final_gain=1.0), ["c3/x", "c3/ctx"], None,
+                  lambda sd: oracle_c3_stack(sd), lambda o, x, c, gz: o.log_prob(x, c).sum()))
+
+    def sample_loss(o, e, c, gz):
+        z, lq = o.sample_from(e, c)
+        return lq.sum() + (z * gz).sum()
+    cases.append(("c3/sample", 2311, dict(final_gain=1.0), ["c3/eps", "c3/ctx"], "c3/gz", lambda sd: oracle_c3_stack(sd), sample_loss))
+    for d in ("forward", "inverse"):
+        cases.append(("affine/" + d, 2321, {}, ["affine/x"], "affine/gz",
+                      lambda sd: OL.AffineCouplingBlock(lambda z: ON.mlp(sd, "flows.1.param_map.", z, 0.0)), plain(d)))
+        cases.append(("masked/" + d, 2331, {}, ["masked/x"], "masked/gz",
+                      lambda sd: OL.MaskedAffine(sd["b"], lambda z: ON.mlp(sd, "s.", z, 0.0), lambda z: ON.mlp(sd, "t.", z, 0.0)),
+                      plain(d)))
+    return cases
+
+
+def g23_reference(fx, tag, n_in):
+    """(names, {prec: (loss, [d loss / d input], {name: d loss / d param})}) of one G23 case."""
+    names = [str(n) for n in fx[tag + "/names"].tolist()]
+    out = {}
+    for prec in ("32", "64"):
+        out[prec] = (float(fx[tag + "/loss" + prec]), [T(fx[tag + "/gin%d_%s" % (i, prec)]) for i in range(n_in)],
+                     {n: T(fx[tag + "/gpar/%s/%s" % (n, prec)]) for n in names})
+    return names, out

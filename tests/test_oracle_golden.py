@@ -410,3 +410,51 @@ def test_g22_masked_affine_autoregressive(tag):
             z, ld = fn(x)
             assert_close(z, fx["%s/%s_z%s" % (tag, dirn, suf)], what=dirn + " z", **tol)
             assert_close(ld, fx["%s/%s_ld%s" % (tag, dirn, suf)], what=dirn + " ld", **tol)
+
+
+# ---------------------------------------------------------------- G23: the reference's own gradients
+def _g23_oracle_grads(fx, case, dt):
+    from helpers import g23_reference
+    tag, seed, gains, in_names, gz_name, make, loss = case
+    sd, _ = state_for(fx, tag, seed, dt, **gains)
+    if tag.startswith("masked"):
+        sd["b"] = T(fx["masked/b"], dt).view(1, -1)
+    names, ref = g23_reference(fx, tag, len(in_names))
+    leaves = {k: (v.clone().requires_grad_() if (v.is_floating_point() and k in names) else v) for k, v in sd.items()}
+    xs = [T(fx[n], dt).requires_grad_() for n in in_names]
+    gz = T(fx[gz_name], dt) if gz_name else None
+    val = loss(make(leaves), *xs, gz)
+    g = torch.autograd.grad(val, xs + [leaves[n] for n in names])
+    return names, ref, val.detach(), g[:len(xs)], g[len(xs):]
+
+
+def _g23_ids():
+    from helpers import g23_cases
+    return [c[0] for c in g23_cases()]
+
+
+@pytest.mark.parametrize("idx", range(8), ids=_g23_ids())
+def test_g23_oracle_autograd_reproduces_reference_gradients(idx):
+    """Gradient parity pinned to the reference: torch autograd over the ORACLE reproduces the
+    gradients the reference's own autograd produced (tests/golden/make_golden.py::g23_gradients) - fp64 to 1e-9
+    relative to the gradient's rms, fp32 within 4x the reference's own fp32-vs-fp64 gradient error + 2e-5 of the rms
+    (different but equivalent fp32 operation orders inside torch's backward formulas)."""
+    from helpers import g23_cases
+    fx = fixture("g23_gradients")
+    case = g23_cases()[idx]
+    for dt, prec in ((torch.float64, "64"), (torch.float32, "32")):
+        names, ref, val, gin, gpar = _g23_oracle_grads(fx, case, dt)
+        loss_ref, gin_ref, gpar_ref = ref[prec]
+        assert abs(float(val) - loss_ref) <= (1e-10 if prec == "64" else 2e-5) * max(1.0, abs(loss_ref))
+        pairs = [("input%d" % i, a, b, ref["64"][1][i]) for i, (a, b) in enumerate(zip(gin, gin_ref))]
+        pairs += [(n, a, gpar_ref[n], ref["64"][2][n]) for n, a in zip(names, gpar)]
+        for lab, got, want, want64 in pairs:
+            rms = float(want64.double().pow(2).mean().sqrt()) + 1e-30
+            err = (got.double() - want.double()).abs()
+            if prec == "64":
+                assert float(err.max()) <= 1e-9 * rms, "%s %s fp64: %.3e (rms %.3e)" % (case[0], lab, float(err.max()), rms)
+            else:
+                noise = (want.double() - want64.double()).abs()
+                bound = 2e-5 * rms + 4.0 * noise + 4.0 * float(noise.mean())
+                bad = float((err > bound).double().mean())
+                assert bad <= 1e-3, "%s %s fp32: %.2f %% outside, max err %.3e, rms %.3e" % (case[0], lab, 100 * bad, float(err.max()), rms)

@@ -111,7 +111,8 @@ class VcnfError(RuntimeError):
 
 
 def lib_path():
-    return _build.LIB
+    """The in-tree library; VCNF_LIB selects another build of it (kernel variants of a measurement, profiles/tools)."""
+    return os.environ.get("VCNF_LIB") or _build.LIB
 
 
 def lib():

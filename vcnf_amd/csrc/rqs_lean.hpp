@@ -138,7 +138,7 @@ __device__ __forceinline__ void rqs_lean_eval(float x, const float (&lg)[3 * K -
     const float fa = 4.f * qa;              // b^2 - 4ac with the rounding error of 4ac recovered (Kahan)
     const float p = fa * qc;
     const float perr = fmaf(fa, qc, -p);
-    const float disc = fmaf(qb, qb, -p) - perr;
+    const float disc = rqs_rounding_level_zero(fmaf(qb, qb, -p) - perr, qb, p);   // rqs_math.hpp: rounding-level negatives are the double root
     bad = bad || (inside && !(disc >= 0.f));              // :164 (the reference asserts)
     const float dd = -qb - hw_sqrt(disc);
     const float rdd = hw_rcp(dd);

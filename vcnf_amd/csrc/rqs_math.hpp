@@ -61,6 +61,20 @@ __device__ __forceinline__ float softplus_f(float v) {
 }
 
 // Selected-bin quantities: left x knot, width, left y knot, height, knot derivatives.
+// b^2 - 4ac of a monotone rational-quadratic bin is positive, but next to a bin edge it equals (h d)^2 while its two
+// terms are of size (2 s h)^2: with a floor-level derivative d ~ 1e-3 beside a steep bin (s ~ 30) the true value is
+// ~1e-9 of the terms - below fp32 resolution - and the rounding of a, b, c (each a few 1e-7 relative) leaves a result of
+// either sign at a few 1e-7 .. 1e-6 of (b^2 + |4ac|).  Seen in the 524 288 x 1024 x 24 shard of config C5 (1.3e10
+// evaluations): one element of layer 18 whose sign depends on the accumulation order of the conditioner's last layer.
+// The reference asserts disc >= 0 on its own fp32 rounding (splines.py:163-164) and would stop on such an element if
+// its rounding fell the same way; here a negative value within 2^-14 of (b^2 + |4ac|) IS the double root (0, the
+// point sits on the bin edge) and is not counted; invalid spline parameters give a discriminant of the order of
+// -(b^2 + |4ac|), which is counted and yields NaN as before.
+__device__ __forceinline__ float rqs_rounding_level_zero(float disc, float qb, float p) {
+  const float scale = fmaf(qb, qb, __builtin_fabsf(p));
+  return (disc < 0.f && disc >= -6.103515625e-5f * scale) ? 0.f : disc;
+}
+
 struct RqsBin {
   float xl, w, yl, h, d0, d1;
 };
@@ -89,7 +103,7 @@ __device__ __forceinline__ void rqs_bin_eval(float x, const RqsBin& b, float& y,
     const float fa = 4.f * qa;
     const float p = fa * qc;
     const float perr = fmaf(fa, qc, -p);
-    const float disc = fmaf(qb, qb, -p) - perr;    // :163
+    const float disc = rqs_rounding_level_zero(fmaf(qb, qb, -p) - perr, qb, p);    // :163
     bad = bad || !(disc >= 0.f);                   // :164 (the reference asserts)
     const float r = div_nr(2.f * qc, -qb - hw_sqrt(disc));   // :166
     y = fmaf(r, b.w, b.xl);                        // :167
