@@ -435,6 +435,38 @@ int vcnf_diag_gaussian_sample_f32(const float* eps, const float* loc, const floa
                                   float log_temperature, float* z, float* logp, int64_t batch,
                                   int32_t features, void* stream);
 
+/* ---- fp64 variants.  The reference's Flow contract is dtype-agnostic and its drivers convert
+ * the model with .double() (/root/reference/run.py:114, rundiag.py:90, runadultvdeq.py:183 over MaskedAffineFlow,
+ * ActNorm and Gaussian bases).  Same contracts as the _f32 entry points of the same name with every float buffer and
+ * scalar a double; elementwise HBM-bound maps only - the fused / matrix-core kernels stay fp32. */
+typedef struct vcnf_rqs_cfg_f64 {
+  int32_t num_bins;
+  int32_t tails;
+  double left, right, bottom, top;
+  double min_bin_width, min_bin_height, min_derivative, wh_scale;
+} vcnf_rqs_cfg_f64;
+int vcnf_rqs_elementwise_f64(const double* x, const double* uw, const double* uh, const double* ud,
+                             int64_t ld_w, int64_t ld_h, int64_t ld_d,
+                             double* y, double* logabsdet, int64_t n,
+                             const vcnf_rqs_cfg_f64* cfg, int inverse, int32_t* bad_disc, void* stream);
+int vcnf_affine_coupling_f64(const double* z, const double* param, double* out, double* logdet,
+                             int64_t batch, int32_t channels, int32_t inner,
+                             int32_t t_off, int32_t d_t, int scale_map, int inverse,
+                             int ld_mode, double ld_sign, void* stream);
+int vcnf_masked_affine_f64(const double* z, const double* s, const double* t, const double* b,
+                           double* out, double* logdet, int64_t batch, int32_t features,
+                           int inverse, int ld_mode, double ld_sign, void* stream);
+int vcnf_affine_const_f64(const double* z, const double* s, const double* t, double* out,
+                          int64_t batch, int32_t channels, int32_t inner, int inverse, void* stream);
+int vcnf_permute_f64(const double* z, const int32_t* idx, double* out,
+                     int64_t batch, int32_t channels, int32_t inner, void* stream);
+int vcnf_diag_gaussian_log_prob_f64(const double* z, const double* loc, const double* log_scale,
+                                    double log_temperature, double* logp, int64_t batch,
+                                    int32_t features, int ld_mode, double ld_sign, void* stream);
+int vcnf_diag_gaussian_sample_f64(const double* eps, const double* loc, const double* log_scale,
+                                  double log_temperature, double* z, double* logp, int64_t batch,
+                                  int32_t features, void* stream);
+
 /* Diagnostic, not on any product path: ONE dense layer y[B, N] = x[B, K] W[N, K]^T + b (nn.Linear,
  * nets/resnet.py:78-106) evaluated with the arithmetic of one of the fused RQS layer kernels' matrix paths, so that
  * the GEMM-level error of each path can be measured against an fp64 product (tests/test_gpu_gemm_error.py):

@@ -15,6 +15,7 @@ from . import build as _build
 
 _P = ctypes.c_void_p
 _I32, _I64, _F32, _INT = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_int
+_F64 = ctypes.c_double
 
 OK = 0
 LD_STORE, LD_ACCUM = 0, 1
@@ -28,6 +29,13 @@ class RqsCfg(ctypes.Structure):
     _fields_ = [("num_bins", _I32), ("tails", _I32), ("left", _F32), ("right", _F32),
                 ("bottom", _F32), ("top", _F32), ("min_bin_width", _F32),
                 ("min_bin_height", _F32), ("min_derivative", _F32), ("wh_scale", _F32)]
+
+
+class RqsCfg64(ctypes.Structure):
+    """struct vcnf_rqs_cfg_f64"""
+    _fields_ = [("num_bins", _I32), ("tails", _I32), ("left", _F64), ("right", _F64),
+                ("bottom", _F64), ("top", _F64), ("min_bin_width", _F64),
+                ("min_bin_height", _F64), ("min_derivative", _F64), ("wh_scale", _F64)]
 
 
 # name -> argtypes, exactly the prototypes of include/vcnf_hip.h
@@ -101,6 +109,14 @@ PROTOTYPES = {
     "vcnf_diag_gaussian_log_prob_f32": ([_P, _P, _P, _F32, _P, _I64, _I32, _INT, _F32, _P], _INT),
     "vcnf_diag_gaussian_sample_f32": ([_P, _P, _P, _F32, _P, _P, _I64, _I32, _P], _INT),
     "vcnf_linear_probe_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _INT, _INT, _P, _P], _INT),
+    "vcnf_rqs_elementwise_f64": ([_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _I64,
+                                  ctypes.POINTER(RqsCfg64), _INT, _P, _P], _INT),
+    "vcnf_affine_coupling_f64": ([_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _INT, _INT, _INT, _F64, _P], _INT),
+    "vcnf_masked_affine_f64": ([_P, _P, _P, _P, _P, _P, _I64, _I32, _INT, _INT, _F64, _P], _INT),
+    "vcnf_affine_const_f64": ([_P, _P, _P, _P, _I64, _I32, _I32, _INT, _P], _INT),
+    "vcnf_permute_f64": ([_P, _P, _P, _I64, _I32, _I32, _P], _INT),
+    "vcnf_diag_gaussian_log_prob_f64": ([_P, _P, _P, _F64, _P, _I64, _I32, _INT, _F64, _P], _INT),
+    "vcnf_diag_gaussian_sample_f64": ([_P, _P, _P, _F64, _P, _P, _I64, _I32, _P], _INT),
 }
 
 _LIB = None
@@ -156,7 +172,7 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def require_device(*tensors, allow_grad=False):
+def require_device(*tensors, allow_grad=False, f64=False):
     """Every tensor must be an fp32 tensor on one HIP device.  Autograd reaches the
     kernels only through vcnf_amd.autograd (the spline VJP kernel); a plain wrapper
     called with a tensor that requires grad raises rather than silently dropping it."""
@@ -166,8 +182,8 @@ def require_device(*tensors, allow_grad=False):
             continue
         if not t.is_cuda:
             raise VcnfError("vcnf_amd computes on MI355X only (tensor on %s); there is no CPU path" % t.device)
-        if t.is_floating_point() and t.dtype != torch.float32:
-            raise VcnfError("vcnf_amd kernels are fp32 (got %s)" % t.dtype)
+        if t.is_floating_point() and t.dtype != torch.float32 and not (f64 and t.dtype == torch.float64):
+            raise VcnfError("this vcnf_amd kernel is fp32%s (got %s)" % (" / fp64" if f64 else "", t.dtype))
         if dev is None:
             dev = t.device
         elif t.device != dev:
@@ -177,6 +193,11 @@ def require_device(*tensors, allow_grad=False):
                 "vcnf_amd: this HIP kernel has no backward pass; evaluate under torch.no_grad() "
                 "(differentiable: the RQS couplings via vcnf_amd.autograd, SURVEY 8f row 1)")
     return dev
+
+
+def _sfx(t):
+    """Entry-point suffix of a tensor's dtype: the elementwise kernels exist for fp32 and fp64."""
+    return "_f64" if t.dtype == torch.float64 else "_f32"
 
 
 def n_derivatives(cfg):
@@ -198,8 +219,12 @@ def make_cfg(num_bins, tails, tail_bound=1.0, left=0.0, right=1.0, bottom=0.0, t
     else:
         # per-feature tail lists: SURVEY 8f row 4, not built
         raise RuntimeError("{} tails are not implemented.".format(tails))
-    return RqsCfg(int(num_bins), mode, float(left), float(right), float(bottom), float(top),
-                  float(min_bin_width), float(min_bin_height), float(min_derivative), float(wh_scale))
+    cfg = RqsCfg(int(num_bins), mode, float(left), float(right), float(bottom), float(top),
+                 float(min_bin_width), float(min_bin_height), float(min_derivative), float(wh_scale))
+    # the same constants at full double precision for the fp64 spline (1e-3 is not a float)
+    cfg.f64 = RqsCfg64(int(num_bins), mode, float(left), float(right), float(bottom), float(top),
+                       float(min_bin_width), float(min_bin_height), float(min_derivative), float(wh_scale))
+    return cfg
 
 
 _BAD = {}
@@ -311,7 +336,7 @@ def check_saturation(device="cuda", model=None):
 # ---------------------------------------------------------------- wrappers
 def rqs_elementwise(x, uw, uh, ud, cfg, inverse, allow_grad=False):
     """x [...]; uw, uh [..., K]; ud [..., K-1 | K+1] (last dim contiguous)."""
-    dev = require_device(x, uw, uh, ud, allow_grad=allow_grad)
+    dev = require_device(x, uw, uh, ud, allow_grad=allow_grad, f64=True)
     shape = x.shape
     k = cfg.num_bins
     nd = n_derivatives(cfg)
@@ -330,12 +355,16 @@ def rqs_elementwise(x, uw, uh, ud, cfg, inverse, allow_grad=False):
     d2, ldd = rows(ud, nd)
     y = torch.empty_like(xf)
     lad = torch.empty_like(xf)
+    f64 = xf.dtype == torch.float64
+    if f64 and not all(t.dtype == torch.float64 for t in (w2, h2, d2)):
+        raise VcnfError("fp64 spline: inputs and logits must all be fp64")
     with torch.cuda.device(dev):
-        st = lib().vcnf_rqs_elementwise_f32(_ptr(xf), _ptr(w2), _ptr(h2), _ptr(d2), ldw, ldh, ldd,
-                                            _ptr(y), _ptr(lad), xf.numel(), ctypes.byref(cfg),
-                                            int(bool(inverse)),
-                                            _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
-    _check(st, "vcnf_rqs_elementwise_f32")
+        fn = lib().vcnf_rqs_elementwise_f64 if f64 else lib().vcnf_rqs_elementwise_f32
+        st = fn(_ptr(xf), _ptr(w2), _ptr(h2), _ptr(d2), ldw, ldh, ldd,
+                _ptr(y), _ptr(lad), xf.numel(), ctypes.byref(cfg.f64 if f64 else cfg),
+                int(bool(inverse)),
+                _ptr(bad_discriminant_counter(dev)) if inverse else None, _stream())
+    _check(st, "vcnf_rqs_elementwise" + _sfx(xf))
     return y.view(shape), lad.view(shape)
 
 
@@ -559,7 +588,9 @@ def rqs_layer_fused(x, context, tf_idx, id_idx, ctx_dim, hidden, num_blocks, pre
 def affine_coupling(z, param, t_off, d_t, scale_map, inverse, logdet=None, sign=1.0):
     """z [B, C, *inner] -> (out, logdet [B] or None when scale_map is NONE and no
     logdet was passed)."""
-    dev = require_device(z, param, logdet)
+    dev = require_device(z, param, logdet, f64=True)
+    if param.dtype != z.dtype or (logdet is not None and logdet.dtype != z.dtype):
+        raise VcnfError("affine_coupling: mixed dtypes")
     z = z.contiguous()
     param = param.contiguous()
     b, c = z.shape[0], z.shape[1]
@@ -569,12 +600,12 @@ def affine_coupling(z, param, t_off, d_t, scale_map, inverse, logdet=None, sign=
     if logdet is None:
         mode = LD_STORE
         if scale_map != SCALE_NONE:
-            logdet = torch.empty(b, dtype=torch.float32, device=dev)
+            logdet = torch.empty(b, dtype=z.dtype, device=dev)
     with torch.cuda.device(dev):
-        st = lib().vcnf_affine_coupling_f32(_ptr(z), _ptr(param), _ptr(out), _ptr(logdet), b, c, inner,
-                                            int(t_off), int(d_t), int(scale_map), int(bool(inverse)),
-                                            mode, float(sign), _stream())
-    _check(st, "vcnf_affine_coupling_f32")
+        st = getattr(lib(), "vcnf_affine_coupling" + _sfx(z))(
+            _ptr(z), _ptr(param), _ptr(out), _ptr(logdet), b, c, inner,
+            int(t_off), int(d_t), int(scale_map), int(bool(inverse)), mode, float(sign), _stream())
+    _check(st, "vcnf_affine_coupling" + _sfx(z))
     return out, logdet
 
 
@@ -702,7 +733,9 @@ def affine_stack_fused(z, wpack, layers, gather_after, gathers, c_in, hidden, sl
 
 
 def masked_affine(z, s, t, bmask, inverse, logdet=None, sign=1.0):
-    dev = require_device(z, s, t, bmask, logdet)
+    dev = require_device(z, s, t, bmask, logdet, f64=True)
+    if any(u is not None and u.dtype != z.dtype for u in (s, t, bmask, logdet)):
+        raise VcnfError("masked_affine: mixed dtypes")
     z = z.contiguous()
     s = s.contiguous() if s is not None else None
     t = t.contiguous() if t is not None else None
@@ -710,12 +743,12 @@ def masked_affine(z, s, t, bmask, inverse, logdet=None, sign=1.0):
     out = torch.empty_like(z)
     mode = LD_ACCUM
     if logdet is None:
-        logdet = torch.empty(b, dtype=torch.float32, device=dev)
+        logdet = torch.empty(b, dtype=z.dtype, device=dev)
         mode = LD_STORE
     with torch.cuda.device(dev):
-        st = lib().vcnf_masked_affine_f32(_ptr(z), _ptr(s), _ptr(t), _ptr(bmask), _ptr(out), _ptr(logdet),
-                                          b, d, int(bool(inverse)), mode, float(sign), _stream())
-    _check(st, "vcnf_masked_affine_f32")
+        st = getattr(lib(), "vcnf_masked_affine" + _sfx(z))(_ptr(z), _ptr(s), _ptr(t), _ptr(bmask), _ptr(out), _ptr(logdet),
+                                                            b, d, int(bool(inverse)), mode, float(sign), _stream())
+    _check(st, "vcnf_masked_affine" + _sfx(z))
     return out, logdet
 
 
@@ -737,15 +770,17 @@ def maf_affine(x, params, inverse):
 
 
 def affine_const(z, s, t, inverse):
-    dev = require_device(z, s, t)
+    dev = require_device(z, s, t, f64=True)
+    if any(u is not None and u.dtype != z.dtype for u in (s, t)):
+        raise VcnfError("affine_const: mixed dtypes")
     z = z.contiguous()
     b, c = z.shape[0], z.shape[1]
     inner = int(z[0, 0].numel()) if z.dim() > 2 else 1
     out = torch.empty_like(z)
     with torch.cuda.device(dev):
-        st = lib().vcnf_affine_const_f32(_ptr(z), _ptr(s), _ptr(t), _ptr(out), b, c, inner,
-                                         int(bool(inverse)), _stream())
-    _check(st, "vcnf_affine_const_f32")
+        st = getattr(lib(), "vcnf_affine_const" + _sfx(z))(_ptr(z), _ptr(s), _ptr(t), _ptr(out), b, c, inner,
+                                                           int(bool(inverse)), _stream())
+    _check(st, "vcnf_affine_const" + _sfx(z))
     return out
 
 
@@ -863,44 +898,48 @@ def channel_mix(z, matrix, shift):
 
 
 def permute(z, idx32):
-    dev = require_device(z)
+    dev = require_device(z, f64=True)
     z = z.contiguous()
     b, c = z.shape[0], z.shape[1]
     inner = int(z[0, 0].numel()) if z.dim() > 2 else 1
     out = torch.empty_like(z)
     with torch.cuda.device(dev):
-        st = lib().vcnf_permute_f32(_ptr(z), _ptr(idx32), _ptr(out), b, c, inner, _stream())
-    _check(st, "vcnf_permute_f32")
+        st = getattr(lib(), "vcnf_permute" + _sfx(z))(_ptr(z), _ptr(idx32), _ptr(out), b, c, inner, _stream())
+    _check(st, "vcnf_permute" + _sfx(z))
     return out
 
 
 def diag_gaussian_log_prob(z, loc, log_scale, temperature=None, logp=None, sign=1.0):
-    dev = require_device(z, loc, log_scale, logp)
+    dev = require_device(z, loc, log_scale, logp, f64=True)
+    if any(u is not None and u.dtype != z.dtype for u in (loc, log_scale, logp)):
+        raise VcnfError("diag_gaussian_log_prob: mixed dtypes")
     b = z.shape[0]
     z2 = z.reshape(b, -1).contiguous()
     mode = LD_ACCUM
     if logp is None:
-        logp = torch.empty(b, dtype=torch.float32, device=dev)
+        logp = torch.empty(b, dtype=z.dtype, device=dev)
         mode = LD_STORE
     lt = 0.0 if temperature is None else math.log(temperature)
     with torch.cuda.device(dev):
-        st = lib().vcnf_diag_gaussian_log_prob_f32(_ptr(z2), _ptr(loc), _ptr(log_scale), lt, _ptr(logp),
-                                                   b, z2.shape[1], mode, float(sign), _stream())
-    _check(st, "vcnf_diag_gaussian_log_prob_f32")
+        st = getattr(lib(), "vcnf_diag_gaussian_log_prob" + _sfx(z))(
+            _ptr(z2), _ptr(loc.contiguous()), _ptr(log_scale.contiguous()), lt, _ptr(logp), b, z2.shape[1], mode, float(sign), _stream())
+    _check(st, "vcnf_diag_gaussian_log_prob" + _sfx(z))
     return logp
 
 
 def diag_gaussian_sample(eps, loc, log_scale, temperature=None):
-    dev = require_device(eps, loc, log_scale)
+    dev = require_device(eps, loc, log_scale, f64=True)
+    if loc.dtype != eps.dtype or log_scale.dtype != eps.dtype:
+        raise VcnfError("diag_gaussian_sample: mixed dtypes")
     b = eps.shape[0]
     e2 = eps.reshape(b, -1).contiguous()
     z = torch.empty_like(e2)
-    logp = torch.empty(b, dtype=torch.float32, device=dev)
+    logp = torch.empty(b, dtype=eps.dtype, device=dev)
     lt = 0.0 if temperature is None else math.log(temperature)
     with torch.cuda.device(dev):
-        st = lib().vcnf_diag_gaussian_sample_f32(_ptr(e2), _ptr(loc), _ptr(log_scale), lt, _ptr(z), _ptr(logp),
-                                                 b, e2.shape[1], _stream())
-    _check(st, "vcnf_diag_gaussian_sample_f32")
+        st = getattr(lib(), "vcnf_diag_gaussian_sample" + _sfx(eps))(
+            _ptr(e2), _ptr(loc.contiguous()), _ptr(log_scale.contiguous()), lt, _ptr(z), _ptr(logp), b, e2.shape[1], _stream())
+    _check(st, "vcnf_diag_gaussian_sample" + _sfx(eps))
     return z.view(eps.shape), logp
 
 

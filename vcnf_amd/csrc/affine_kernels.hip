@@ -14,14 +14,24 @@ namespace vcnf {
 
 constexpr int kBlock = 256;
 
-__device__ __forceinline__ float group_sum(float v, int G) {
+// The kernels below that the reference's fp64 drivers reach (runadultvdeq.py:101-108,183: model.double() over
+// MaskedAffineFlow / ActNorm / DiagGaussian stacks) are templates on the scalar type; the fp32 instantiations are the
+// code they always were, the fp64 ones use the double-precision library functions.
+template <typename T>
+__device__ __forceinline__ T group_sum(T v, int G) {
   for (int m = G >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
 }
 
-__device__ __forceinline__ void put_ld(float* ld, long long b, float v, int mode) {
+template <typename T>
+__device__ __forceinline__ void put_ld(T* ld, long long b, T v, int mode) {
   ld[b] = mode ? ld[b] + v : v;
 }
+
+__device__ __forceinline__ float exp_(float v) { return expf(v); }
+__device__ __forceinline__ double exp_(double v) { return exp(v); }
+__device__ __forceinline__ float log_(float v) { return logf(v); }
+__device__ __forceinline__ double log_(double v) { return log(v); }
 
 // lanes per sample for a row of n elements
 static int pick_lanes(long long n) {
@@ -41,20 +51,24 @@ static dim3 grid_for(long long batch, int G) {
 // torch.sigmoid and log(sigmoid) evaluated like the reference does
 // (flows/affine/coupling.py:128-136): sigma = 1/(1+exp(-v)), then log(sigma).
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-v)); }
+__device__ __forceinline__ double sigmoid_f(double v) { return 1.0 / (1.0 + exp(-v)); }
 
 // ------------------------------------------------------------------ affine coupling
-struct AffineArgs {
-  const float* z;
-  const float* param;
-  float* out;
-  float* logdet;
+template <typename T>
+struct AffineArgsT {
+  const T* z;
+  const T* param;
+  T* out;
+  T* logdet;
   long long B;
   int C, inner, t_off, d_t;
   int scale_map, inverse, G, ld_mode;
-  float ld_sign;
+  T ld_sign;
 };
+using AffineArgs = AffineArgsT<float>;
 
-__global__ __launch_bounds__(kBlock) void affine_coupling_kernel(const AffineArgs a) {
+template <typename T>
+__global__ __launch_bounds__(kBlock) void affine_coupling_kernel(const AffineArgsT<T> a) {
   const int g = threadIdx.x & (a.G - 1);
   const int per_block = kBlock / a.G;
   const long long row = (long long)a.C * a.inner;          // elements of one sample
@@ -63,27 +77,27 @@ __global__ __launch_bounds__(kBlock) void affine_coupling_kernel(const AffineArg
   const int npar = a.scale_map == VCNF_SCALE_NONE ? 1 : 2;
   for (long long b = (long long)blockIdx.x * per_block + threadIdx.x / a.G; b < a.B;
        b += (long long)gridDim.x * per_block) {
-    const float* zr = a.z + b * row;
-    float* orow = a.out + b * row;
-    const float* pr = a.param + b * (long long)npar * t_n;
-    float acc = 0.f;
+    const T* zr = a.z + b * row;
+    T* orow = a.out + b * row;
+    const T* pr = a.param + b * (long long)npar * t_n;
+    T acc = 0;
     for (long long e = g; e < row; e += a.G) {
-      float v = zr[e];
+      T v = zr[e];
       const long long te = e - t_lo;
       if (te >= 0 && te < t_n) {
         if (npar == 1) {                                   // coupling.py:139-141 / :165-167
-          const float p = pr[te];
+          const T p = pr[te];
           v = a.inverse ? v - p : v + p;
         } else {
           const long long c = te / a.inner, i = te - c * a.inner;
-          const float shift = pr[(2 * c) * a.inner + i];   // param[:, 0::2]
-          const float sc = pr[(2 * c + 1) * a.inner + i];  // param[:, 1::2]
+          const T shift = pr[(2 * c) * a.inner + i];   // param[:, 0::2]
+          const T sc = pr[(2 * c + 1) * a.inner + i];  // param[:, 1::2]
           if (a.scale_map == VCNF_SCALE_EXP) {             // :124-126 / :150-152
-            if (a.inverse) { v = (v - shift) * expf(-sc); acc -= sc; }
-            else { v = v * expf(sc) + shift; acc += sc; }
+            if (a.inverse) { v = (v - shift) * exp_(-sc); acc -= sc; }
+            else { v = v * exp_(sc) + shift; acc += sc; }
           } else {
-            const float sg = sigmoid_f(sc + 2.f);
-            const float lg = logf(sg);
+            const T sg = sigmoid_f(sc + T(2));
+            const T lg = log_(sg);
             const bool divide = (a.scale_map == VCNF_SCALE_SIGMOID) != (a.inverse != 0);
             if (a.inverse) v = divide ? (v - shift) / sg : (v - shift) * sg;
             else v = divide ? v / sg + shift : v * sg + shift;
@@ -132,35 +146,38 @@ __global__ __launch_bounds__(kBlock) void maf_affine_kernel(const MafArgs a) {
 }
 
 // ------------------------------------------------------------------ masked affine
-struct MaskedArgs {
-  const float *z, *s, *t, *b;
-  float* out;
-  float* logdet;
+template <typename T>
+struct MaskedArgsT {
+  const T *z, *s, *t, *b;
+  T* out;
+  T* logdet;
   long long B;
   int D, inverse, G, ld_mode;
-  float ld_sign;
+  T ld_sign;
 };
+using MaskedArgs = MaskedArgsT<float>;
 
-__global__ __launch_bounds__(kBlock) void masked_affine_kernel(const MaskedArgs a) {
+template <typename T>
+__global__ __launch_bounds__(kBlock) void masked_affine_kernel(const MaskedArgsT<T> a) {
   const int g = threadIdx.x & (a.G - 1);
   const int per_block = kBlock / a.G;
-  const float nanv = __builtin_nanf("");
+  const T nanv = (T)__builtin_nanf("");
   for (long long r = (long long)blockIdx.x * per_block + threadIdx.x / a.G; r < a.B;
        r += (long long)gridDim.x * per_block) {
-    float acc = 0.f;
+    T acc = 0;
     for (int j = g; j < a.D; j += a.G) {
       const long long e = r * a.D + j;
-      const float m = a.b[j];
-      const float zv = a.z[e];
-      float sc = a.s ? a.s[e] : 0.f;
-      float tr = a.t ? a.t[e] : 0.f;
+      const T m = a.b[j];
+      const T zv = a.z[e];
+      T sc = a.s ? a.s[e] : T(0);
+      T tr = a.t ? a.t[e] : T(0);
       sc = isfinite(sc) ? sc : nanv;                       // coupling.py:205-208
       tr = isfinite(tr) ? tr : nanv;
-      const float zm = m * zv;
-      const float om = 1.f - m;
-      float v;
-      if (a.inverse) v = zm + om * (zv - tr) * expf(-sc);  // :220
-      else v = zm + om * (zv * expf(sc) + tr);             // :209
+      const T zm = m * zv;
+      const T om = T(1) - m;
+      T v;
+      if (a.inverse) v = zm + om * (zv - tr) * exp_(-sc);  // :220
+      else v = zm + om * (zv * exp_(sc) + tr);             // :209
       a.out[e] = v;
       acc += om * sc;                                      // :210 / :221
     }
@@ -170,31 +187,37 @@ __global__ __launch_bounds__(kBlock) void masked_affine_kernel(const MaskedArgs 
 }
 
 // ------------------------------------------------------------------ per-channel affine, gather
-struct ConstArgs {
-  const float *z, *s, *t;
-  float* out;
+template <typename T>
+struct ConstArgsT {
+  const T *z, *s, *t;
+  T* out;
   long long total;
   int C, inner, inverse;
 };
+using ConstArgs = ConstArgsT<float>;
 
-__global__ __launch_bounds__(kBlock) void affine_const_kernel(const ConstArgs a) {
+template <typename T>
+__global__ __launch_bounds__(kBlock) void affine_const_kernel(const ConstArgsT<T> a) {
   for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < a.total; e += (long long)gridDim.x * kBlock) {
     const int c = (int)((e / a.inner) % a.C);
-    const float s = a.s ? a.s[c] : 0.f, t = a.t ? a.t[c] : 0.f;
-    const float v = a.z[e];
-    a.out[e] = a.inverse ? (v - t) * expf(-s) : v * expf(s) + t;   // coupling.py:38 / :47
+    const T s = a.s ? a.s[c] : T(0), t = a.t ? a.t[c] : T(0);
+    const T v = a.z[e];
+    a.out[e] = a.inverse ? (v - t) * exp_(-s) : v * exp_(s) + t;   // coupling.py:38 / :47
   }
 }
 
-struct PermArgs {
-  const float* z;
+template <typename T>
+struct PermArgsT {
+  const T* z;
   const int32_t* idx;
-  float* out;
+  T* out;
   long long total;
   int C, inner;
 };
+using PermArgs = PermArgsT<float>;
 
-__global__ __launch_bounds__(kBlock) void permute_kernel(const PermArgs a) {
+template <typename T>
+__global__ __launch_bounds__(kBlock) void permute_kernel(const PermArgsT<T> a) {
   const long long row = (long long)a.C * a.inner;
   for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < a.total; e += (long long)gridDim.x * kBlock) {
     const long long b = e / row;
@@ -206,30 +229,33 @@ __global__ __launch_bounds__(kBlock) void permute_kernel(const PermArgs a) {
 }
 
 // ------------------------------------------------------------------ diagonal Gaussian
-struct GaussArgs {
-  const float *in, *loc, *log_scale;
-  float* z;
-  float* logp;
+template <typename T>
+struct GaussArgsT {
+  const T *in, *loc, *log_scale;
+  T* z;
+  T* logp;
   long long B;
   int D, G, ld_mode, sample;
-  float log_temp, ld_sign, norm;   // norm = -0.5 * D * log(2 pi)
+  T log_temp, ld_sign, norm;   // norm = -0.5 * D * log(2 pi)
 };
+using GaussArgs = GaussArgsT<float>;
 
-__global__ __launch_bounds__(kBlock) void diag_gaussian_kernel(const GaussArgs a) {
+template <typename T>
+__global__ __launch_bounds__(kBlock) void diag_gaussian_kernel(const GaussArgsT<T> a) {
   const int g = threadIdx.x & (a.G - 1);
   const int per_block = kBlock / a.G;
   for (long long r = (long long)blockIdx.x * per_block + threadIdx.x / a.G; r < a.B;
        r += (long long)gridDim.x * per_block) {
-    float acc = 0.f;
+    T acc = 0;
     for (int j = g; j < a.D; j += a.G) {
-      const float ls = a.log_scale[j] + a.log_temp;
-      const float v = a.in[r * a.D + j];
+      const T ls = a.log_scale[j] + a.log_temp;
+      const T v = a.in[r * a.D + j];
       if (a.sample) {                                      // base.py:639-641
-        a.z[r * a.D + j] = a.loc[j] + expf(ls) * v;
-        acc += ls + 0.5f * v * v;
+        a.z[r * a.D + j] = a.loc[j] + exp_(ls) * v;
+        acc += ls + T(0.5) * v * v;
       } else {                                             // base.py:649-651
-        const float u = (v - a.loc[j]) / expf(ls);
-        acc += ls + 0.5f * u * u;
+        const T u = (v - a.loc[j]) / exp_(ls);
+        acc += ls + T(0.5) * u * u;
       }
     }
     acc = group_sum(acc, a.G);
@@ -375,7 +401,7 @@ extern "C" int vcnf_affine_coupling_f32(const float* z, const float* param, floa
   if (scale_map != VCNF_SCALE_NONE && !logdet) return VCNF_ERR_NULL;
   AffineArgs a{z, param, out, logdet, batch, channels, inner, t_off, d_t, scale_map, inverse ? 1 : 0,
                pick_lanes((long long)channels * inner), ld_mode, ld_sign};
-  hipLaunchKernelGGL(affine_coupling_kernel, grid_for(batch, a.G), dim3(kBlock), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(affine_coupling_kernel<float>, grid_for(batch, a.G), dim3(kBlock), 0, (hipStream_t)stream, a);
   return launched();
 }
 
@@ -399,7 +425,7 @@ extern "C" int vcnf_masked_affine_f32(const float* z, const float* s, const floa
   if (batch == 0) return VCNF_OK;
   if (!z || !b || !out || !logdet) return VCNF_ERR_NULL;
   MaskedArgs a{z, s, t, b, out, logdet, batch, features, inverse ? 1 : 0, pick_lanes(features), ld_mode, ld_sign};
-  hipLaunchKernelGGL(masked_affine_kernel, grid_for(batch, a.G), dim3(kBlock), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(masked_affine_kernel<float>, grid_for(batch, a.G), dim3(kBlock), 0, (hipStream_t)stream, a);
   return launched();
 }
 
@@ -411,7 +437,7 @@ extern "C" int vcnf_affine_const_f32(const float* z, const float* s, const float
   ConstArgs a{z, s, t, out, batch * (long long)channels * inner, channels, inner, inverse ? 1 : 0};
   long long blocks = (a.total + kBlock - 1) / kBlock;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(affine_const_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(affine_const_kernel<float>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
   return launched();
 }
 
@@ -423,7 +449,7 @@ extern "C" int vcnf_permute_f32(const float* z, const int32_t* idx, float* out,
   PermArgs a{z, idx, out, batch * (long long)channels * inner, channels, inner};
   long long blocks = (a.total + kBlock - 1) / kBlock;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(permute_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(permute_kernel<float>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
   return launched();
 }
 
@@ -450,7 +476,7 @@ static int gauss(const float* in, const float* loc, const float* log_scale, floa
     case 2: hipLaunchKernelGGL(diag_gaussian_cols_kernel<2>, grid, dim3(kBlock), 0, st, a); break;
     case 3: hipLaunchKernelGGL(diag_gaussian_cols_kernel<3>, grid, dim3(kBlock), 0, st, a); break;
     case 4: hipLaunchKernelGGL(diag_gaussian_cols_kernel<4>, grid, dim3(kBlock), 0, st, a); break;
-    default: hipLaunchKernelGGL(diag_gaussian_kernel, grid, dim3(kBlock), 0, st, a); break;
+    default: hipLaunchKernelGGL(diag_gaussian_kernel<float>, grid, dim3(kBlock), 0, st, a); break;
   }
   return launched();
 }
@@ -465,4 +491,82 @@ extern "C" int vcnf_diag_gaussian_sample_f32(const float* eps, const float* loc,
                                              float log_temperature, float* z, float* logp, int64_t batch,
                                              int32_t features, void* stream) {
   return gauss(eps, loc, log_scale, log_temperature, z, logp, batch, features, VCNF_LD_STORE, 1.f, 1, stream);
+}
+
+// ------------------------------------------------------------------ fp64 entry points (same contracts, T = double)
+extern "C" int vcnf_affine_coupling_f64(const double* z, const double* param, double* out, double* logdet,
+                                        int64_t batch, int32_t channels, int32_t inner,
+                                        int32_t t_off, int32_t d_t, int scale_map, int inverse,
+                                        int ld_mode, double ld_sign, void* stream) {
+  if (batch < 0 || channels < 1 || inner < 1 || t_off < 0 || d_t < 0 || t_off + d_t > channels) return VCNF_ERR_SHAPE;
+  if (scale_map < VCNF_SCALE_EXP || scale_map > VCNF_SCALE_NONE) return VCNF_ERR_UNSUPPORTED;
+  if (!ok_ld(ld_mode)) return VCNF_ERR_UNSUPPORTED;
+  if (batch == 0) return VCNF_OK;
+  if (!z || !out || (d_t > 0 && !param)) return VCNF_ERR_NULL;
+  if (scale_map != VCNF_SCALE_NONE && !logdet) return VCNF_ERR_NULL;
+  AffineArgsT<double> a{z, param, out, logdet, batch, channels, inner, t_off, d_t, scale_map, inverse ? 1 : 0,
+                        pick_lanes((long long)channels * inner), ld_mode, ld_sign};
+  hipLaunchKernelGGL(affine_coupling_kernel<double>, grid_for(batch, a.G), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return launched();
+}
+
+extern "C" int vcnf_masked_affine_f64(const double* z, const double* s, const double* t, const double* b,
+                                      double* out, double* logdet, int64_t batch, int32_t features,
+                                      int inverse, int ld_mode, double ld_sign, void* stream) {
+  if (batch < 0 || features < 1) return VCNF_ERR_SHAPE;
+  if (!ok_ld(ld_mode)) return VCNF_ERR_UNSUPPORTED;
+  if (batch == 0) return VCNF_OK;
+  if (!z || !b || !out || !logdet) return VCNF_ERR_NULL;
+  MaskedArgsT<double> a{z, s, t, b, out, logdet, batch, features, inverse ? 1 : 0, pick_lanes(features), ld_mode, ld_sign};
+  hipLaunchKernelGGL(masked_affine_kernel<double>, grid_for(batch, a.G), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return launched();
+}
+
+extern "C" int vcnf_affine_const_f64(const double* z, const double* s, const double* t, double* out,
+                                     int64_t batch, int32_t channels, int32_t inner, int inverse, void* stream) {
+  if (batch < 0 || channels < 1 || inner < 1) return VCNF_ERR_SHAPE;
+  if (batch == 0) return VCNF_OK;
+  if (!z || !out) return VCNF_ERR_NULL;
+  ConstArgsT<double> a{z, s, t, out, batch * (long long)channels * inner, channels, inner, inverse ? 1 : 0};
+  long long blocks = (a.total + kBlock - 1) / kBlock;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(affine_const_kernel<double>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return launched();
+}
+
+extern "C" int vcnf_permute_f64(const double* z, const int32_t* idx, double* out,
+                                int64_t batch, int32_t channels, int32_t inner, void* stream) {
+  if (batch < 0 || channels < 1 || inner < 1) return VCNF_ERR_SHAPE;
+  if (batch == 0) return VCNF_OK;
+  if (!z || !idx || !out) return VCNF_ERR_NULL;
+  PermArgsT<double> a{z, idx, out, batch * (long long)channels * inner, channels, inner};
+  long long blocks = (a.total + kBlock - 1) / kBlock;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(permute_kernel<double>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return launched();
+}
+
+static int gauss64(const double* in, const double* loc, const double* log_scale, double log_temperature,
+                   double* z, double* logp, int64_t batch, int32_t features, int ld_mode, double ld_sign,
+                   int sample, void* stream) {
+  if (batch < 0 || features < 1) return VCNF_ERR_SHAPE;
+  if (!ok_ld(ld_mode)) return VCNF_ERR_UNSUPPORTED;
+  if (batch == 0) return VCNF_OK;
+  if (!in || !loc || !log_scale || !logp || (sample && !z)) return VCNF_ERR_NULL;
+  GaussArgsT<double> a{in, loc, log_scale, z, logp, batch, features, pick_lanes(features), ld_mode, sample,
+                       log_temperature, ld_sign, -0.5 * (double)features * log(2.0 * M_PI)};
+  hipLaunchKernelGGL(diag_gaussian_kernel<double>, grid_for(batch, a.G), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return launched();
+}
+
+extern "C" int vcnf_diag_gaussian_log_prob_f64(const double* z, const double* loc, const double* log_scale,
+                                               double log_temperature, double* logp, int64_t batch,
+                                               int32_t features, int ld_mode, double ld_sign, void* stream) {
+  return gauss64(z, loc, log_scale, log_temperature, nullptr, logp, batch, features, ld_mode, ld_sign, 0, stream);
+}
+
+extern "C" int vcnf_diag_gaussian_sample_f64(const double* eps, const double* loc, const double* log_scale,
+                                             double log_temperature, double* z, double* logp, int64_t batch,
+                                             int32_t features, void* stream) {
+  return gauss64(eps, loc, log_scale, log_temperature, z, logp, batch, features, VCNF_LD_STORE, 1.0, 1, stream);
 }

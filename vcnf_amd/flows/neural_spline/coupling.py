@@ -102,7 +102,12 @@ class PiecewiseRationalQuadraticCDF(Flow):
             raise ValueError('Expected inputs of shape [B, {}], got {}.'.format(
                 tuple(self.unnormalized_widths.shape[:-1]), tuple(inputs.shape)))
         splines._check_bins(self.num_bins, self.min_bin_width, self.min_bin_height)
-        if autograd.needs_grad(inputs, *self.logits()):
+        if inputs.dtype == torch.float64:
+            # fp64 models (the reference's drivers call .double()): the elementwise fp64 spline on the logit rows
+            # expanded over the batch (no gradient path in fp64; csrc/rqs_f64.hip)
+            uw, uh, ud = (t.unsqueeze(0).expand((inputs.shape[0],) + tuple(t.shape)) for t in self.logits())
+            out, lad = _lib.rqs_elementwise(inputs, uw, uh, ud, self._cfg(), inverse)
+        elif autograd.needs_grad(inputs, *self.logits()):
             return autograd.rqs_shared(inputs, *self.logits(), self._cfg(), inverse=inverse)
         else:
             # one logit row per position, shared by the batch: read in place (no [B, ...] expansion)
@@ -338,7 +343,8 @@ class PiecewiseRationalQuadraticCoupling(Flow):
 
     def _run(self, inputs, context, sampling, log_q=None, sign=1.0):
         self._check(inputs)
-        if self.per_feature:
+        if self.per_feature or (inputs.dtype == torch.float64 and inputs.dim() == 2):
+            # fp64: the plain structure of coupling.py:70-125 over the fp64 elementwise spline (csrc/rqs_f64.hip)
             out, lad = self._run_per_feature(inputs, context, sampling)
             if log_q is not None:
                 return out, log_q.add_(lad, alpha=sign)

@@ -39,7 +39,7 @@ def _linears_uncached(mlp):
 
 
 def eligible(block, z):
-    if z.dim() != 2 or block.split_mode not in ('channel', 'channel_inv'):
+    if z.dim() != 2 or z.dtype != torch.float32 or block.split_mode not in ('channel', 'channel_inv'):
         return False
     core = block.flows[1]
     got = _linears(core.param_map)
