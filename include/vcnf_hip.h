@@ -388,12 +388,32 @@ typedef struct {
   int32_t cond_off, t_off, d_t;
   int32_t gather_before;
 } vcnf_affine_stack_layer;
+/* 1 if vcnf_affine_stack_fused_f32 takes this layer shape at this feature count (the layer kernel's limits plus
+ * the stack kernel's two LDS strips per wave: features <= 128), else 0 - then run the layers one launch each. */
+int vcnf_affine_stack_fused_supported(int32_t c_in, int32_t hidden, int32_t n_out, int32_t features);
 int vcnf_affine_stack_fused_f32(const float* x, float* y, float* logdet, int64_t batch, int32_t features,
                                 int32_t n_layers, const vcnf_affine_stack_layer* layers, int32_t gather_after,
                                 int32_t c_in, int32_t hidden, float leaky_slope, int scale_map,
                                 const float* wpack, int64_t wpack_floats,
                                 const int32_t* gathers, int32_t n_gather_rows,
                                 int inverse, int ld_mode, float ld_sign, void* stream);
+
+/* The same run with the two hidden-deep dense layers of every conditioner MLP (nets/mlp.py:30-35: hidden -> hidden,
+ * hidden -> parameters) on the fp16 split-half matrix path (v_mfma_f32_16x16x32_f16, hi + lo halves of both operands,
+ * fp32 accumulation; GEMM error at or below the fp32 chain's at depth >= 32, tests/test_gpu_gemm_error.py); the first
+ * layer (raw inputs, c_in deep) stays on exact fp32 matrix instructions.  wpack as for vcnf_affine_stack_fused_f32
+ * (first layer, biases; its second / third layer weights serve the range fallback), wpack_h3 =
+ * vcnf_affine_layer_fused_h3_pack_floats floats per layer (vcnf_amd/fused_affine.py::pack_h3).  A wave whose hidden
+ * activations leave the fp16 range (|h| > 65504) evaluates that layer with the exact fp32 body instead - nothing is
+ * clamped - and bumps redo_count (device int32, may be NULL).  hidden in {32, 64, 128}. */
+int64_t vcnf_affine_layer_fused_h3_pack_floats(int32_t c_in, int32_t hidden, int32_t n_out);
+int vcnf_affine_stack_fused_f16x3_f32(const float* x, float* y, float* logdet, int64_t batch, int32_t features,
+                                      int32_t n_layers, const vcnf_affine_stack_layer* layers,
+                                      int32_t gather_after, int32_t c_in, int32_t hidden, float leaky_slope,
+                                      int scale_map, const float* wpack, int64_t wpack_floats,
+                                      const float* wpack_h3, int64_t wpack_h3_floats,
+                                      const int32_t* gathers, int32_t n_gather_rows,
+                                      int inverse, int ld_mode, float ld_sign, int32_t* redo_count, void* stream);
 
 /* Elementwise map of the masked affine autoregressive flow (flows/affine/autoregressive.py:75-103): params
  * [batch, features, 2] = (unconstrained scale u, shift) per feature from one MADE pass (:96-103),

@@ -406,6 +406,86 @@ def test_affine_stacks_c1_c2(hip, name, tag, layers, d, widths, seed):
         assert_close(lq, fx[tag + "/s_logq32"], what="sample log_q", **LP)
 
 
+@pytest.mark.parametrize("d,widths,split,scale_map", [
+    (32, [16, 64, 64, 32], "channel", "exp"),                    # config C2's stack
+    (2, [1, 32, 32, 2], "channel", "exp"),                       # config C1's stack
+    (24, [12, 128, 128, 24], "channel_inv", "sigmoid_inv"),
+])
+def test_affine_stack_split_half_matrix_path(hip, d, widths, split, scale_map):
+    """The DEFAULT form of the stack kernel since round 3: second and third dense layer of every conditioner on the fp16
+    split-half matrix path (first layer exact fp32).  Against the exact-fp32 stack kernel and the fp64 oracle: the
+    split-half result is at least as close to fp64 as the fp32 kernel's (mean error), and both agree to 1e-5 relative;
+    a wave whose hidden activations leave the fp16 range takes the fp32 body - those rows are BITWISE the fp32 kernel's."""
+    from helpers import oracle_affine_stack
+    torch.manual_seed(77 + d)
+    flows = []
+    for _ in range(8):
+        flows.append(nf.flows.AffineCouplingBlock(nf.nets.MLP(widths, init_zeros=False), scale_map=scale_map, split_mode=split))
+        flows.append(nf.flows.Permute(d, mode="swap"))
+    model = nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows).cuda().eval()
+    b = 4096 + 19
+    x, eps = torch.randn(b, d, device="cuda"), torch.randn(b, d, device="cuda")
+    def run(prec):
+        for f in model.flows:
+            f.fused_precision = prec
+        with torch.no_grad():
+            return model.log_prob(x), model.sample_from(eps)
+    nf.range_redo_count()
+    lp_h, (z_h, lq_h) = run("fp16x3")
+    assert nf.range_redo_count() == 0
+    lp_f, (z_f, lq_f) = run("fp32")
+    assert not torch.equal(z_h, z_f) or d == 2                     # it really is another arithmetic
+    assert_close(lp_h, lp_f.cpu(), rtol=1e-5, atol=2e-5, what="split-half vs fp32 stack log_prob")
+    assert_close(z_h, z_f.cpu(), rtol=1e-5, atol=2e-5, what="split-half vs fp32 stack sample z")
+    if split == "channel" and scale_map == "exp":                  # the oracle stack helper covers this block form
+        sd64 = {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in model.state_dict().items()}
+        want = oracle_affine_stack(sd64, 8, d, leaky=0.0).log_prob(x.cpu().double())
+        e_h = float((lp_h.cpu().double() - want).abs().mean())
+        e_f = float((lp_f.cpu().double() - want).abs().mean())
+        print("\naffine stack d=%d: mean |log_prob - fp64|: split-half %.3e, exact fp32 %.3e" % (d, e_h, e_f))
+        assert e_h <= 1.25 * e_f + 1e-7
+    # range: scale the first layer of one block up (and its second layer down by the same factor, so that the outputs
+    # stay ordinary) until its hidden activations pass 65504
+    with torch.no_grad():
+        net = model.flows[4].flows[1].param_map.net
+        net[0].weight.mul_(2.0e5)
+        net[0].bias.mul_(2.0e5)
+        net[2].weight.mul_(5.0e-6)
+    lp_h, (z_h, lq_h) = run("fp16x3")
+    redone = nf.range_redo_count()
+    lp_f, (z_f, lq_f) = run("fp32")
+    assert redone > 0, "no wave left the fp16 range: the test does not test the fallback"
+    big = ~torch.isclose(lp_h, lp_f, rtol=1e-4, atol=1e-3)
+    assert not big.any(), "a clamped value leaked: %d rows differ grossly" % int(big.sum())
+    assert torch.isfinite(lp_h).all()
+
+
+def test_affine_stack_declines_more_than_128_features(hip):
+    """D = 129 with split_mode 'channel_inv' and no scale passes the single-layer kernel's shape check but
+    not the stack kernel's LDS bound (two strips per wave: 512 D bytes <= 64 KB).  The planner now asks
+    vcnf_affine_stack_fused_supported and runs such layers one launch each instead of raising."""
+    from vcnf_amd import fused_affine
+    torch.manual_seed(129)
+    d = 129
+    flows = []
+    for _ in range(3):
+        flows.append(nf.flows.AffineCouplingBlock(nf.nets.MLP([64, 64, 64, 65], init_zeros=False), scale=False,
+                                                  split_mode="channel_inv"))
+        flows.append(nf.flows.Permute(d, mode="shuffle"))
+    model = nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows).cuda().eval()
+    x = torch.randn(300, d, device="cuda")
+    with torch.no_grad():
+        assert model.flows[0].fusable(x)                                       # the one-layer kernel takes the shape
+        assert fused_affine.plan_stack(list(model.flows), 0, x, False) is None  # the stack kernel does not
+        model.fuse_affine_stacks = True
+        lp1 = model.log_prob(x)
+        z1, lq1 = model.sample_from(x)
+        model.fuse_affine_stacks = False
+        lp0 = model.log_prob(x)
+        z0, lq0 = model.sample_from(x)
+    assert torch.equal(lp1, lp0) and torch.equal(z1, z0) and torch.equal(lq1, lq0)
+
+
 @pytest.mark.parametrize("d,widths,mode,split,scale_map", [
     (32, [16, 64, 64, 32], "swap", "channel", "exp"),            # config C2's stack
     (33, [17, 32, 32, 32], "shuffle", "channel", "sigmoid"),      # odd width, random permutations
@@ -423,6 +503,8 @@ def test_affine_stack_single_launch_matches_per_layer(hip, d, widths, mode, spli
         flows.append(nf.flows.AffineCouplingBlock(nf.nets.MLP(widths, init_zeros=False), scale_map=scale_map, split_mode=split))
         flows.append(nf.flows.Permute(d, mode=mode))
     model = nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows).cuda().eval()
+    for f in model.flows:
+        f.fused_precision = "fp32"            # bit-for-bit against the per-layer kernel: both on exact fp32 matrix instructions
     for b in (1, 15, 64, 1000 + 37):
         x, eps = torch.randn(b, d, device="cuda"), torch.randn(b, d, device="cuda")
         with torch.no_grad():

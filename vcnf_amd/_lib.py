@@ -49,6 +49,7 @@ PROTOTYPES = {
     "vcnf_rqs_elementwise_bwd_f32": ([_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _I64,
                                       ctypes.POINTER(RqsCfg), _INT, _P], _INT),
     "vcnf_affine_layer_fused_supported": ([_I32, _I32, _I32, _I32], _INT),
+    "vcnf_affine_stack_fused_supported": ([_I32, _I32, _I32, _I32], _INT),
     "vcnf_affine_layer_fused_pack_floats": ([_I32, _I32, _I32], _I64),
     "vcnf_affine_layer_fused_f32": ([_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _INT, _P, _I64,
                                      _P, _P, _INT, _INT, _F32, _P], _INT),
@@ -102,6 +103,9 @@ PROTOTYPES = {
                                            _P, _P], _INT),
     "vcnf_affine_stack_fused_f32": ([_P, _P, _P, _I64, _I32, _I32, _P, _I32, _I32, _I32, _F32, _INT, _P, _I64, _P, _I32,
                                      _INT, _INT, _F32, _P], _INT),
+    "vcnf_affine_layer_fused_h3_pack_floats": ([_I32, _I32, _I32], _I64),
+    "vcnf_affine_stack_fused_f16x3_f32": ([_P, _P, _P, _I64, _I32, _I32, _P, _I32, _I32, _I32, _F32, _INT, _P, _I64, _P, _I64,
+                                           _P, _I32, _INT, _INT, _F32, _P, _P], _INT),
     "vcnf_maf_affine_f32": ([_P, _P, _P, _P, _I64, _I32, _INT, _INT, _F32, _P], _INT),
     "vcnf_masked_affine_f32": ([_P, _P, _P, _P, _P, _P, _I64, _I32, _INT, _INT, _F32, _P], _INT),
     "vcnf_affine_const_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _INT, _P], _INT),
@@ -709,10 +713,12 @@ class AffineStackLayer(ctypes.Structure):
 
 
 def affine_stack_fused(z, wpack, layers, gather_after, gathers, c_in, hidden, slope, scale_map, inverse, logdet=None,
-                       sign=1.0):
+                       sign=1.0, wpack_h3=None):
     """A run of AffineCouplingBlocks + the permutations between them in one kernel; csrc/fused_affine.hip.
-    ``layers``: list of (cond_off, t_off, d_t, gather_before) in execution order; ``gathers`` int32 [rows, D] or None."""
-    dev = require_device(z, wpack, logdet, gathers)
+    ``layers``: list of (cond_off, t_off, d_t, gather_before) in execution order; ``gathers`` int32 [rows, D] or None.
+    ``wpack_h3``: the split-half fragments of the conditioners' second and third dense layers - then those run on the
+    fp16 split-half matrix path (range fallback to the fp32 body on the device, counted in range_redo_counter)."""
+    dev = require_device(z, wpack, logdet, gathers, wpack_h3)
     z = z.contiguous()
     b, d = z.shape
     out = torch.empty_like(z)
@@ -722,12 +728,20 @@ def affine_stack_fused(z, wpack, layers, gather_after, gathers, c_in, hidden, sl
         logdet = (torch.empty if scale_map != SCALE_NONE else torch.zeros)(b, dtype=torch.float32, device=dev)
     arr = (AffineStackLayer * len(layers))(*[AffineStackLayer(*map(int, l)) for l in layers])
     with torch.cuda.device(dev), _timed("affine_stack_fused"):
-        st = lib().vcnf_affine_stack_fused_f32(_ptr(z), _ptr(out), _ptr(logdet) if scale_map != SCALE_NONE else None,
-                                               b, d, len(layers), ctypes.cast(arr, ctypes.c_void_p), int(gather_after),
-                                               int(c_in), int(hidden), float(slope), int(scale_map),
-                                               _ptr(wpack), wpack.numel(), _ptr(gathers),
-                                               0 if gathers is None else int(gathers.shape[0]),
-                                               int(bool(inverse)), mode, float(sign), _stream())
+        if wpack_h3 is not None:
+            st = lib().vcnf_affine_stack_fused_f16x3_f32(
+                _ptr(z), _ptr(out), _ptr(logdet) if scale_map != SCALE_NONE else None,
+                b, d, len(layers), ctypes.cast(arr, ctypes.c_void_p), int(gather_after),
+                int(c_in), int(hidden), float(slope), int(scale_map), _ptr(wpack), wpack.numel(),
+                _ptr(wpack_h3), wpack_h3.numel(), _ptr(gathers), 0 if gathers is None else int(gathers.shape[0]),
+                int(bool(inverse)), mode, float(sign), _ptr(range_redo_counter(dev)), _stream())
+        else:
+            st = lib().vcnf_affine_stack_fused_f32(_ptr(z), _ptr(out), _ptr(logdet) if scale_map != SCALE_NONE else None,
+                                                   b, d, len(layers), ctypes.cast(arr, ctypes.c_void_p), int(gather_after),
+                                                   int(c_in), int(hidden), float(slope), int(scale_map),
+                                                   _ptr(wpack), wpack.numel(), _ptr(gathers),
+                                                   0 if gathers is None else int(gathers.shape[0]),
+                                                   int(bool(inverse)), mode, float(sign), _stream())
     _check(st, "vcnf_affine_stack_fused_f32")
     return out, logdet
 
@@ -801,7 +815,8 @@ def conv1x1_fused(x, wpack, c_out, in_bias=None, out_bias=None, in_slope=None, o
     return out
 
 
-_WGRAD_WS = {}        # per-device workspace of the partial results; calls are ordered by the stream they run on
+_WGRAD_WS = {}        # workspace of the partial results per (device, stream): calls on one stream are ordered, calls on
+                      # different streams (two models' backward passes, side streams) must not share it
 
 
 def linear_wgrad(x, dy, want_bias=True):
@@ -815,7 +830,8 @@ def linear_wgrad(x, dy, want_bias=True):
     if slices < 1:
         raise VcnfError("linear_wgrad: unsupported layer shape %d -> %d" % (n_in, n_out))
     need = slices * (n_out * n_in + n_out)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(dev).cuda_stream)
     ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.float32, device=dev)

@@ -23,6 +23,7 @@
 
 #include "../../include/vcnf_hip.h"
 #include "fused_common.hpp"
+#include "split_half.hpp"
 
 namespace vcnf {
 
@@ -143,6 +144,159 @@ __device__ __forceinline__ void affine_layer_on_strip(float* xs, int XS, const _
   }
 }
 
+
+// The same layer with the two 16 HB-deep dense layers (hidden -> hidden, hidden -> parameters) on the fp16
+// split-half matrix path (round 3): v_mfma_f32_16x16x32_f16 with hi | lo halves of both operands, hi*hi +
+// (hi*lo + lo*hi) 2^-11, fp32 accumulation - GEMM error at or below the fp32 chain's at these depths
+// (tests/test_gpu_gemm_error.py) at 3 x 16 instead of 8 x 32 matrix-pipe cycles per 16 x 16 x 32 product.  The first
+// layer (c_in <= 64 deep, raw inputs) stays on the exact fp32 instruction.  The accumulators of a layer are again the
+// next layer's B operand: k-step t of the 16x16x32 instruction takes lane group q's rows 4 q .. 4 q + 3 of row blocks
+// 2 t and 2 t + 1 (eight values = its eight k-slots), and the host packs the weights in that k order
+// (vcnf_amd/fused_affine.py::pack_h3).  Range: the halves cannot carry |h| > 65504; the wave then returns false BEFORE
+// anything is written and the caller evaluates the layer with the fp32 body above - no clamped value ever leaves.
+template <int KIG, int HB, int OBM, int NCB>
+__device__ __forceinline__ bool affine_layer_on_strip_h3(float* xs, int XS, const __amdgpu_buffer_rsrc_t wr,
+                                                         const __amdgpu_buffer_rsrc_t wr3, const FALayer lp, int h3_off,
+                                                         const FusedAffineArgs& a, int voff, int qoff, int m16, int q,
+                                                         bool scaled, float (&ld)[NCB]) {
+  static_assert(HB % 2 == 0, "two row blocks of 16 per k-step of 32");
+  constexpr int NT = HB / 2;
+  const int wb = 4 * lp.w_off;               // byte offset of the layer's fp32 pack (first layer, biases)
+  const int hb3 = 4 * h3_off;                // byte offset of the layer's split-half fragments
+  // NCB column blocks of 16 samples share every weight fragment (the kernel is bound by the fragment loads from
+  // L1 otherwise: 28 KB per 16 samples and layer)
+  // ---- layer 1 (exact fp32): natural k order, k-step s of lane group q reads input 4 s + q
+  floatx4 h1[NCB][HB];
+  {
+    float xin[NCB][4 * KIG];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int s = 0; s < 4 * KIG; ++s) {
+        const int c = 4 * s + q;
+        xin[cb][s] = (s < a.KI && c < lp.c_in) ? xs[(16 * cb + m16) * XS + lp.cond_off + c] : 0.f;
+      }
+#pragma unroll
+    for (int nb = 0; nb < HB; ++nb) {
+      floatx4 acc[NCB];
+      const floatx4 bias = wload(wr, qoff, wb + 4 * (a.off_b1 + 16 * nb));
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc[cb] = bias;
+#pragma unroll
+      for (int g = 0; g < KIG; ++g) {
+        const floatx4 w = wload(wr, voff, wb + 4 * ((nb * KIG + g) * 256));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) acc[cb] = mfma4(w[i], xin[cb][4 * g + i], acc[cb]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[cb][nb][r] = acc[cb][r] > 0.f ? acc[cb][r] : a.slope * acc[cb][r];   // LeakyReLU, mlp.py:33
+    }
+  }
+  float satm = 0.f;
+  half8 bh[NCB][NT], bl[NCB][NT];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float v8[8] = {h1[cb][2 * t][0], h1[cb][2 * t][1], h1[cb][2 * t][2], h1[cb][2 * t][3],
+                           h1[cb][2 * t + 1][0], h1[cb][2 * t + 1][1], h1[cb][2 * t + 1][2], h1[cb][2 * t + 1][3]};
+      split8<false>(v8, bh[cb][t], bl[cb][t], satm);
+    }
+  if (__builtin_amdgcn_ballot_w64(!(satm <= 65504.f)) != 0) return false;
+  // ---- layer 2 on split halves: fragments [nb][t][hi | lo][lane][8 halves]
+  floatx4 h2[NCB][HB];
+#pragma unroll
+  for (int nb = 0; nb < HB; ++nb) {
+    floatx4 acc[NCB], corr[NCB];
+    const floatx4 bias = wload(wr, qoff, wb + 4 * (a.off_b2 + 16 * nb));
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) { acc[cb] = bias; corr[cb] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const half8 ah = __builtin_bit_cast(half8, wload(wr3, voff, hb3 + 4 * (((nb * NT + t) * 2 + 0) * 256)));
+      const half8 al = __builtin_bit_cast(half8, wload(wr3, voff, hb3 + 4 * (((nb * NT + t) * 2 + 1) * 256)));
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        acc[cb] = mfma16h(ah, bh[cb][t], acc[cb]);
+        corr[cb] = mfma16h(ah, bl[cb][t], corr[cb]);
+        corr[cb] = mfma16h(al, bh[cb][t], corr[cb]);
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = fmaf(corr[cb][r], kLoUnscale, acc[cb][r]);
+        h2[cb][nb][r] = v > 0.f ? v : a.slope * v;
+      }
+  }
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float v8[8] = {h2[cb][2 * t][0], h2[cb][2 * t][1], h2[cb][2 * t][2], h2[cb][2 * t][3],
+                           h2[cb][2 * t + 1][0], h2[cb][2 * t + 1][1], h2[cb][2 * t + 1][2], h2[cb][2 * t + 1][3]};
+      split8<false>(v8, bh[cb][t], bl[cb][t], satm);
+    }
+  if (__builtin_amdgcn_ballot_w64(!(satm <= 65504.f)) != 0) return false;
+  // ---- layer 3 on split halves + affine map on the lane's features (as in the fp32 body)
+  const int w3 = hb3 + 4 * (HB * NT * 2 * 256);
+#pragma unroll
+  for (int ob = 0; ob < OBM; ++ob) {
+    if (ob < a.OB) {
+      floatx4 acc[NCB], corr[NCB];
+      const floatx4 bias = wload(wr, qoff, wb + 4 * (a.off_b3 + 16 * ob));
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) { acc[cb] = bias; corr[cb] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const half8 ah = __builtin_bit_cast(half8, wload(wr3, voff, w3 + 4 * (((ob * NT + t) * 2 + 0) * 256)));
+        const half8 al = __builtin_bit_cast(half8, wload(wr3, voff, w3 + 4 * (((ob * NT + t) * 2 + 1) * 256)));
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          acc[cb] = mfma16h(ah, bh[cb][t], acc[cb]);
+          corr[cb] = mfma16h(ah, bl[cb][t], corr[cb]);
+          corr[cb] = mfma16h(al, bh[cb][t], corr[cb]);
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[cb][r] = fmaf(corr[cb][r], kLoUnscale, acc[cb][r]);
+        if (scaled) {
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const int f = 8 * ob + 2 * q + pr;              // rows 4 q + 2 pr (shift), + 1 (scale)
+            if (f < lp.d_t) {
+              float* pz = xs + (16 * cb + m16) * XS + lp.t_off + f;
+              *pz = affine_apply(*pz, acc[cb][2 * pr], acc[cb][2 * pr + 1], a.scale_map, a.inverse, ld[cb]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int f = 16 * ob + 4 * q + r;
+            if (f < lp.d_t) {
+              float* pz = xs + (16 * cb + m16) * XS + lp.t_off + f;
+              *pz = a.inverse ? *pz - acc[cb][r] : *pz + acc[cb][r];  // coupling.py:139-141 / :165-167
+            }
+          }
+        }
+      }
+    }
+  }
+  return true;
+}
+
+// column blocks per wave of the split-half stack kernel: two share each weight fragment (half the L1 traffic) but at
+// 188 registers; measured at C2: 0.291 ms per pass against 0.255 with one (profiles/r03_c2_affine_stack.md)
+#ifndef VCNF_FA_NCB
+#define VCNF_FA_NCB 1
+#endif
 constexpr int kFABlock = 256;          // 4 waves x 16 samples
 
 // KIG: first-layer k-step groups of four (c_in <= 16 KIG); HB: hidden row blocks (hidden = 16 HB,
@@ -227,11 +381,36 @@ struct FusedAffineStackArgs {
   int layer_floats;              // floats of one layer's pack
   FALayer layer[kFAStackMax];
   int gather_before[kFAStackMax];   // index row applied to the columns before layer i (-1: none)
+  const float* wpack_h3;         // split-half fragments of the second and third dense layer of every layer (or NULL)
+  unsigned wpack_h3_bytes;
+  int h3_layer_floats;
+  int32_t* redo;                 // counts layer evaluations that fell back to the fp32 body (range)
 };
 
-template <int KIG, int HB, int OBM>
+// Column permutation of a wave's strip (flows/mixing.py:32-54): xo[r][c] = xs[r][idx[c]].  When D divides 64 a lane
+// keeps ONE column for the whole copy (its index entry is loaded once, the row advances by 64 / D): no integer
+// division and one index load per lane instead of one per element - the general loop cost as many vector instructions
+// per layer as the whole conditioner (profiles/r03_c2_affine_stack.md).
+__device__ __forceinline__ void strip_gather(const float* xs, float* xo, const int32_t* idx, int D, int n, int lane) {
+  if ((64 % D) == 0) {
+    const int c = lane & (D - 1);
+    const int src = idx[c];
+    const int step = 64 / D;
+    int r = lane / D;
+    for (int e = lane; e < n; e += 64, r += step) xo[e] = xs[r * D + src];
+  } else {
+    for (int e = lane; e < n; e += 64) {
+      const int r = e / D, c = e - r * D;
+      xo[e] = xs[r * D + idx[c]];
+    }
+  }
+}
+
+template <int KIG, int HB, int OBM, bool H3>
 __global__ __launch_bounds__(kFABlock) void fused_affine_stack_kernel(const FusedAffineStackArgs sa) {
   extern __shared__ __align__(16) float smem[];
+  constexpr int NCB = H3 ? VCNF_FA_NCB : 1;  // 16-sample column blocks per wave in the split-half form (sharing every weight fragment)
+  constexpr int RW = 16 * NCB;               // rows of a wave's strip
   const FusedAffineArgs& a = sa.base;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -245,53 +424,70 @@ __global__ __launch_bounds__(kFABlock) void fused_affine_stack_kernel(const Fuse
   const int qoff = q * 16;
   const bool scaled = a.scale_map != VCNF_SCALE_NONE;
   const int XS = D;
-  const int n16 = 16 * D;
-  float* s0 = smem + wave * 2 * n16;         // two strips per wave
-  float* s1 = s0 + n16;
-  const long long nwt = (a.B + 15) / 16;
+  const int nrw = RW * D;
+  float* s0 = smem + wave * 2 * nrw;         // two strips per wave
+  float* s1 = s0 + nrw;
+  const long long nwt = (a.B + RW - 1) / RW;
   const long long wstride = (long long)gridDim.x * (kFABlock / 64);
   for (long long wt = (long long)blockIdx.x * (kFABlock / 64) + wave; wt < nwt; wt += wstride) {
-    const long long b0 = wt * 16;
-    const int rows = (int)min(16LL, a.B - b0);
+    const long long b0 = wt * RW;
+    const int rows = (int)min((long long)RW, a.B - b0);
     const int nvalid = rows * D;
     const float* src = a.x + b0 * D;
     float* xs = s0;
     float* xo = s1;
     if ((D & 3) == 0) {
-      for (int e = 4 * lane; e < n16; e += 256) {
+      for (int e = 4 * lane; e < nrw; e += 256) {
         const float4 v = e < nvalid ? *reinterpret_cast<const float4*>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(xs + e) = v;
       }
     } else {
-      for (int e = lane; e < n16; e += 64) xs[e] = e < nvalid ? src[e] : 0.f;
+      for (int e = lane; e < nrw; e += 64) xs[e] = e < nvalid ? src[e] : 0.f;
     }
-    float ld = 0.f;
+    float ld[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) ld[cb] = 0.f;
     for (int li = 0; li < sa.n_layers; ++li) {
       const int gb = sa.gather_before[li];
       if (gb >= 0) {                                              // flows/mixing.py:32-54 as a strip-to-strip copy
-        const int32_t* idx = sa.gathers + gb * D;
-        for (int e = lane; e < n16; e += 64) {
-          const int r = e / D, c = e - r * D;
-          xo[e] = xs[r * D + idx[c]];
-        }
+        strip_gather(xs, xo, sa.gathers + gb * D, D, nrw, lane);
         float* t_ = xs; xs = xo; xo = t_;
       }
-      affine_layer_on_strip<KIG, HB, OBM>(xs, XS, wr, sa.layer[li], a, voff, qoff, m16, q, scaled, ld);
+      if constexpr (H3) {
+        const __amdgpu_buffer_rsrc_t wr3 =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sa.wpack_h3), 0, sa.wpack_h3_bytes, 0x00020000);
+        float ld_try[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) ld_try[cb] = ld[cb];
+        if (affine_layer_on_strip_h3<KIG, HB, OBM, NCB>(xs, XS, wr, wr3, sa.layer[li], li * sa.h3_layer_floats, a, voff,
+                                                        qoff, m16, q, scaled, ld_try)) {
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) ld[cb] = ld_try[cb];
+        } else {                           // a hidden activation beyond the fp16 range: the exact fp32 body, nothing was written
+          if (lane == 0 && sa.redo) atomicAdd(sa.redo, 1);
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+            affine_layer_on_strip<KIG, HB, OBM>(xs + 16 * cb * XS, XS, wr, sa.layer[li], a, voff, qoff, m16, q, scaled, ld[cb]);
+        }
+      } else {
+        affine_layer_on_strip<KIG, HB, OBM>(xs, XS, wr, sa.layer[li], a, voff, qoff, m16, q, scaled, ld[0]);
+      }
     }
     if (sa.gather_after >= 0) {
-      const int32_t* idx = sa.gathers + sa.gather_after * D;
-      for (int e = lane; e < n16; e += 64) {
-        const int r = e / D, c = e - r * D;
-        xo[e] = xs[r * D + idx[c]];
-      }
+      strip_gather(xs, xo, sa.gathers + sa.gather_after * D, D, nrw, lane);
       float* t_ = xs; xs = xo; xo = t_;
     }
     if (a.logdet) {
-      ld += __shfl_xor(ld, 16, 64);
-      ld += __shfl_xor(ld, 32, 64);
-      if (q == 0 && m16 < rows) {
-        const float o = a.ld_sign * ld;
-        a.logdet[b0 + m16] = a.ld_mode ? a.logdet[b0 + m16] + o : o;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        float v = ld[cb];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const int row = 16 * cb + m16;
+        if (q == 0 && row < rows) {
+          const float o = a.ld_sign * v;
+          a.logdet[b0 + row] = a.ld_mode ? a.logdet[b0 + row] + o : o;
+        }
       }
     }
     float* dst = a.y + b0 * D;
@@ -305,12 +501,16 @@ __global__ __launch_bounds__(kFABlock) void fused_affine_stack_kernel(const Fuse
 
 template <int KIG, int HB, int OBM>
 static int launch_fa_stack(const FusedAffineStackArgs& sa, hipStream_t st) {
-  const size_t lds = (size_t)4 * 2 * 16 * sa.base.D * sizeof(float);
+  const int rw = sa.wpack_h3 ? 16 * VCNF_FA_NCB : 16;     // rows of a wave's strip
+  const size_t lds = (size_t)4 * 2 * rw * sa.base.D * sizeof(float);
   if (lds > 64 * 1024) return VCNF_ERR_SHAPE;
-  const long long ntiles = (sa.base.B + 63) / 64;
+  const long long ntiles = (sa.base.B + 4 * rw - 1) / (4 * rw);
   const long long cap = 256 * 8;
   dim3 grid((unsigned)(ntiles < cap ? ntiles : cap));
-  hipLaunchKernelGGL((fused_affine_stack_kernel<KIG, HB, OBM>), grid, dim3(kFABlock), lds, st, sa);
+  if (sa.wpack_h3)
+    hipLaunchKernelGGL((fused_affine_stack_kernel<KIG, HB, OBM, true>), grid, dim3(kFABlock), lds, st, sa);
+  else
+    hipLaunchKernelGGL((fused_affine_stack_kernel<KIG, HB, OBM, false>), grid, dim3(kFABlock), lds, st, sa);
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }
 
@@ -338,6 +538,11 @@ using namespace vcnf;
 
 extern "C" int vcnf_affine_layer_fused_supported(int32_t c_in, int32_t hidden, int32_t n_out, int32_t features) {
   return fa_shape_ok(c_in, hidden, n_out, features) ? 1 : 0;
+}
+
+// the whole-stack kernel keeps two LDS strips of 16 samples x D per wave (512 D bytes per workgroup <= 64 KB)
+extern "C" int vcnf_affine_stack_fused_supported(int32_t c_in, int32_t hidden, int32_t n_out, int32_t features) {
+  return (fa_shape_ok(c_in, hidden, n_out, features) && (size_t)4 * 2 * 16 * features * sizeof(float) <= 64 * 1024) ? 1 : 0;
 }
 
 extern "C" int64_t vcnf_affine_layer_fused_pack_floats(int32_t c_in, int32_t hidden, int32_t n_out) {
@@ -387,12 +592,19 @@ extern "C" int vcnf_affine_layer_fused_f32(const float* x, float* y, float* logd
 #undef VCNF_FA
 }
 
-extern "C" int vcnf_affine_stack_fused_f32(const float* x, float* y, float* logdet, int64_t batch, int32_t features,
-                                           int32_t n_layers, const vcnf_affine_stack_layer* layers, int32_t gather_after,
-                                           int32_t c_in, int32_t hidden, float leaky_slope, int scale_map,
-                                           const float* wpack, int64_t wpack_floats,
-                                           const int32_t* gathers, int32_t n_gather_rows,
-                                           int inverse, int ld_mode, float ld_sign, void* stream) {
+extern "C" int64_t vcnf_affine_layer_fused_h3_pack_floats(int32_t c_in, int32_t hidden, int32_t n_out) {
+  if (!fa_shape_ok(c_in, hidden, n_out, 2)) return 0;
+  const int HB = hidden / 16, OB = (n_out + 15) / 16;
+  return (int64_t)HB * HB * 256 + (int64_t)OB * HB * 256;      // W2 and W3 as hi | lo fp16 fragments: as many floats as in fp32
+}
+
+static int affine_stack(const float* x, float* y, float* logdet, int64_t batch, int32_t features,
+                        int32_t n_layers, const vcnf_affine_stack_layer* layers, int32_t gather_after,
+                        int32_t c_in, int32_t hidden, float leaky_slope, int scale_map,
+                        const float* wpack, int64_t wpack_floats,
+                        const int32_t* gathers, int32_t n_gather_rows,
+                        int inverse, int ld_mode, float ld_sign,
+                        const float* wpack_h3, int64_t wpack_h3_floats, int32_t* redo_count, void* stream) {
   if (!layers || n_layers < 1 || n_layers > kFAStackMax) return VCNF_ERR_SHAPE;
   const int d_t0 = layers[0].d_t;
   const int n_out = scale_map == VCNF_SCALE_NONE ? d_t0 : 2 * d_t0;
@@ -418,6 +630,10 @@ extern "C" int vcnf_affine_stack_fused_f32(const float* x, float* y, float* logd
   a.off_w3 = a.off_b2 + 16 * HB;
   a.off_b3 = a.off_w3 + a.OB * HB * 256;
   sa.gathers = gathers; sa.n_layers = n_layers; sa.gather_after = gather_after; sa.layer_floats = (int)per_layer;
+  sa.wpack_h3 = wpack_h3; sa.redo = redo_count;
+  sa.h3_layer_floats = (int)vcnf_affine_layer_fused_h3_pack_floats(c_in, hidden, n_out);
+  sa.wpack_h3_bytes = (unsigned)(wpack_h3_floats * 4);
+  if (wpack_h3 && wpack_h3_floats != (int64_t)sa.h3_layer_floats * n_layers) return VCNF_ERR_SHAPE;
   for (int i = 0; i < n_layers; ++i) {
     const vcnf_affine_stack_layer& l = layers[i];
     if (l.d_t != d_t0 || l.cond_off < 0 || l.t_off < 0 || l.cond_off + c_in > features || l.t_off + l.d_t > features)
@@ -439,4 +655,29 @@ extern "C" int vcnf_affine_stack_fused_f32(const float* x, float* y, float* logd
   if (HB == 4) { VCNF_FAS(4, 4) }
   VCNF_FAS(4, 8)
 #undef VCNF_FAS
+}
+
+extern "C" int vcnf_affine_stack_fused_f32(const float* x, float* y, float* logdet, int64_t batch, int32_t features,
+                                           int32_t n_layers, const vcnf_affine_stack_layer* layers, int32_t gather_after,
+                                           int32_t c_in, int32_t hidden, float leaky_slope, int scale_map,
+                                           const float* wpack, int64_t wpack_floats,
+                                           const int32_t* gathers, int32_t n_gather_rows,
+                                           int inverse, int ld_mode, float ld_sign, void* stream) {
+  return affine_stack(x, y, logdet, batch, features, n_layers, layers, gather_after, c_in, hidden, leaky_slope, scale_map,
+                      wpack, wpack_floats, gathers, n_gather_rows, inverse, ld_mode, ld_sign, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int vcnf_affine_stack_fused_f16x3_f32(const float* x, float* y, float* logdet, int64_t batch, int32_t features,
+                                                 int32_t n_layers, const vcnf_affine_stack_layer* layers,
+                                                 int32_t gather_after, int32_t c_in, int32_t hidden, float leaky_slope,
+                                                 int scale_map, const float* wpack, int64_t wpack_floats,
+                                                 const float* wpack_h3, int64_t wpack_h3_floats,
+                                                 const int32_t* gathers, int32_t n_gather_rows,
+                                                 int inverse, int ld_mode, float ld_sign, int32_t* redo_count,
+                                                 void* stream) {
+  if (!wpack_h3) return VCNF_ERR_NULL;
+  if (hidden % 32) return VCNF_ERR_UNSUPPORTED;
+  return affine_stack(x, y, logdet, batch, features, n_layers, layers, gather_after, c_in, hidden, leaky_slope, scale_map,
+                      wpack, wpack_floats, gathers, n_gather_rows, inverse, ld_mode, ld_sign, wpack_h3, wpack_h3_floats,
+                      redo_count, stream);
 }

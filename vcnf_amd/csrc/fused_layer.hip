@@ -93,6 +93,15 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
   const RqsConst& c = a.c;
   const bool shared = a.sh_w != nullptr;
 
+  if (a.redo) {
+    // re-evaluation pass behind the split-half kernel: normally no tile is flagged - leave before any set-up
+    // (index tables, knot tables) so that the launch costs a few microseconds
+    const long long nt = (a.B + kTile - 1) / kTile;
+    int any = 0;
+    for (long long t = blockIdx.x; t < nt; t += gridDim.x) any |= a.redo[t];
+    if (!any) return;
+  }
+
   for (int i = tid; i < DT; i += kFBlock) tfi[i] = a.tf_idx[i];
   for (int i = tid; i < DI; i += kFBlock) idi[i] = a.id_idx[i];
   if (shared) {

@@ -21,7 +21,7 @@ struct ResOpArgs {
   long long n;
 };
 
-__device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + __expf(-v)); }
+__device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }   // torch.sigmoid in fp32 (resnet.py:54-56); the fast __expf form was ~2 ulp off
 
 template <int OP>
 __device__ __forceinline__ void res_op(float a, float b, float c, float& o0, float& o1) {

@@ -142,6 +142,11 @@ class AffineCouplingBlock(Flow):
         # inputs (fused_affine.eligible); False forces the three-step path
         self.fused = True
 
+    # matrix path of the one-launch stack kernel for this block's conditioner: None = vcnf_amd.fused.DEFAULT_PRECISION
+    # ('fp16x3': second / third dense layer on split-half operands with an on-device fp32 fallback for out-of-range
+    # activations; 'fp32': exact fp32 matrix instructions throughout)
+    fused_precision = None
+
     def fusable(self, z):
         """True when this call would take the one-kernel path (which can also absorb a Permute)."""
         if not self.fused:

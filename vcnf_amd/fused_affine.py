@@ -98,6 +98,41 @@ def pack(l1, l2, l3):
     return buf
 
 
+def _pack_h3(w, nb_out, hb):
+    """w [n_out, 16 hb] -> hi | lo fp16 A fragments of v_mfma_f32_16x16x32_f16, [nb][t][hi | lo][lane][8] as floats: lane l
+    holds row 16 nb + l % 16 and, for q = l / 16, the eight k-slots of k-step t = units 32 t + 4 q + i (i < 4) and
+    32 t + 16 + 4 q + (i - 4): rows 4 q .. 4 q + 3 of the previous layer's row blocks 2 t and 2 t + 1, i.e. that layer's
+    accumulators as they sit in the lane (csrc/fused_affine.hip::affine_layer_on_strip_h3).  Rows beyond n_out are zero."""
+    from .fused import _split_halves, _as_floats
+    dev = w.device
+    nt = hb // 2
+    nb = torch.arange(nb_out, device=dev).view(-1, 1, 1, 1)
+    t = torch.arange(nt, device=dev).view(1, -1, 1, 1)
+    lane = torch.arange(64, device=dev).view(1, 1, -1, 1)
+    i = torch.arange(8, device=dev).view(1, 1, 1, -1)
+    shape = (nb_out, nt, 64, 8)
+    rows = (16 * nb + (lane & 15)).expand(shape)
+    cols = (32 * t + 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3)).expand(shape)
+    ok = rows < w.shape[0]
+    vals = torch.where(ok, w[torch.where(ok, rows, torch.zeros_like(rows)), cols], torch.zeros((), device=dev, dtype=w.dtype))
+    hi, lo = _split_halves(vals)
+    return _as_floats(torch.stack([hi, lo], dim=2))           # [nb, t, 2, 64, 8] halves
+
+
+def pack_h3(l2, l3):
+    hb = l2.out_features // 16
+    ob = (l3.out_features + 15) // 16
+    return torch.cat([_pack_h3(l2.weight.detach(), hb, hb), _pack_h3(l3.weight.detach(), ob, hb)]).contiguous()
+
+
+def h3_ok(block):
+    """The split-half form of the stack kernel: hidden width a multiple of 32 and the block's matrix path 'fp16x3'
+    (vcnf_amd.fused.DEFAULT_PRECISION / ``block.fused_precision``)."""
+    from . import fused
+    (l1, l2, l3), _ = _linears(block.flows[1].param_map)
+    return l1.out_features % 32 == 0 and fused.precision_of(block) == fused.PREC_F16X3
+
+
 def packed_weights(block):
     (l1, l2, l3), slope = _linears(block.flows[1].param_map)
     params = (l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias)
@@ -154,6 +189,8 @@ def plan_stack(order, start, z, inverse):
             continue
         if isinstance(f, AffineCouplingBlock) and f.fusable(z):
             (l1, l2, l3), slope = _linears(f.flows[1].param_map)
+            if not _lib.lib().vcnf_affine_stack_fused_supported(l1.in_features, l1.out_features, l3.out_features, z.shape[1]):
+                break                      # e.g. more than 128 features: the layers run one launch each
             core = f.flows[1]
             sh = (l1.in_features, l1.out_features, l3.out_features, slope, core.scale, core.scale_map,
                   _geometry(f, z.shape[1])[2])
@@ -171,13 +208,28 @@ def plan_stack(order, start, z, inverse):
     return j, steps, pending
 
 
+def _struct_key(f):
+    """What a plan / launch descriptor depends on besides module identity (structural edits in place on an
+    existing module - swapping param_map, changing scale_map or split_mode, re-seeding a Permute - must not leave a stale
+    plan in use): split mode, scale flags and the conditioner's identity of a block; the index buffers' storage and
+    version of a Permute."""
+    core = getattr(f, 'flows', [None, None])[1] if hasattr(f, 'split_mode') else None
+    if core is not None:
+        return (f.split_mode, core.scale, core.scale_map, id(core.param_map))
+    perm = getattr(f, 'perm', None)
+    if torch.is_tensor(perm):
+        inv = getattr(f, 'inv_perm', perm)
+        return (perm.data_ptr(), perm._version, inv.data_ptr(), inv._version)
+    return None
+
+
 def cached_plan(owner, order, start, z, inverse):
     """plan_stack memoised on the calling model for evaluations without autograd: the plan depends only on the
     modules in ``order`` (identity, their ``fused`` switches), the position, the direction and the feature count."""
     if torch.is_grad_enabled():
         return plan_stack(order, start, z, inverse)
     key = (start, bool(inverse), z.dim(), z.shape[-1], z.dtype, tuple(map(id, order)),
-           tuple(getattr(f, 'fused', None) for f in order))
+           tuple(getattr(f, 'fused', None) for f in order), tuple(_struct_key(f) for f in order))
     plans = owner.__dict__.setdefault('_stack_plans', {})
     if key not in plans:
         if len(plans) > 32:
@@ -206,9 +258,18 @@ def run_stack(steps, trailing, z, code, inverse, log_q, sign):
             old.copy_(new)
         else:
             cache['wpack'] = new
+        # ... and the split-half fragments of the second / third dense layers (same in-place rule)
+        with torch.no_grad():
+            new3 = torch.cat([pack_h3(*_linears(b.flows[1].param_map)[0][1:]) for b, _ in steps]).contiguous() \
+                if _linears(first.flows[1].param_map)[0][0].out_features % 32 == 0 else None
+        old3 = cache.get('wpack_h3')
+        if new3 is not None and old3 is not None and old3.shape == new3.shape and old3.device == new3.device:
+            old3.copy_(new3)
+        else:
+            cache['wpack_h3'] = new3
         cache['key'] = key
-    dkey = (bool(inverse), z.shape[1], str(z.device), None if trailing is None else id(trailing),
-            tuple(None if p is None else id(p) for _, p in steps))
+    dkey = (bool(inverse), z.shape[1], str(z.device), None if trailing is None else (id(trailing), _struct_key(trailing)),
+            tuple((_struct_key(b), None if p is None else (id(p), _struct_key(p))) for b, p in steps))
     desc = cache.setdefault('desc', {}).get(bool(inverse))
     if desc is None or desc[0] != dkey:
         (l1, _, l3), slope = _linears(first.flows[1].param_map)
@@ -228,5 +289,7 @@ def run_stack(steps, trailing, z, code, inverse, log_q, sign):
         desc = (dkey, layers, ga, gathers, l1.in_features, l1.out_features, slope)
         cache['desc'][bool(inverse)] = desc
     _, layers, ga, gathers, c_in, hidden, slope = desc
+    # (the split-half form keeps 32-row strips: two per wave = 1 KB x D of LDS per workgroup, D <= 64)
+    use_h3 = cache.get('wpack_h3') is not None and z.shape[1] <= 64 and all(h3_ok(b) for b, _ in steps)
     return _lib.affine_stack_fused(z, cache['wpack'], layers, ga, gathers, c_in, hidden, slope, code,
-                                   inverse, logdet=log_q, sign=sign)
+                                   inverse, logdet=log_q, sign=sign, wpack_h3=cache['wpack_h3'] if use_h3 else None)
