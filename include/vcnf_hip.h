@@ -339,12 +339,13 @@ int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t ctx_dim, i
  * 16- and 48-deep layers, fp32 accumulation; GEMM error at or below the F32 path's on
  * every layer shape, tests/test_gpu_gemm_error.py).  The halves cannot carry a value
  * beyond +-65504 or a non-finite input.  redo_tiles (device int32, one entry per
- * vcnf_rqs_layer_fused_tile_rows() = 128 consecutive samples, may be NULL) makes the pair
- * of calls below range-safe WITHOUT a host round trip:
- *   F16X3 call: redo_tiles is OUTPUT - 1 for a tile that held such a value, and then no
- *     y row and no logdet entry of that tile is written; 0 otherwise.
+ * vcnf_rqs_layer_fused_tile_rows() = 32 consecutive samples, ceil(batch / 32) entries, may
+ * be NULL) makes the pair of calls below range-safe WITHOUT a host round trip:
+ *   F16X3 call: redo_tiles is OUTPUT - 1 for the rows of a tile that held such a value
+ *     (the kernel's tile is 32 samples for small batches, 128 = four entries otherwise),
+ *     and then no y row and no logdet entry of that tile is written; 0 otherwise.
  *   F32 call with the same arguments (and the F32 packing of the same weights):
- *     redo_tiles is INPUT - only the flagged tiles are evaluated.
+ *     redo_tiles is INPUT - only the flagged rows are evaluated and written.
  * After both, every sample has fp32-range results (the reference is plain fp32,
  * nets/resnet.py:92-106).  With redo_tiles == NULL the F16X3 call clamps at +-65504 and
  * stores.  sat_count (device int32, may be NULL) is incremented once per out-of-range tile
@@ -353,6 +354,12 @@ int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t ctx_dim, i
  * softmax / softplus / sigmoid exponentials folded in (vcnf_amd/fused.py::pack_layer_h3),
  * cfg->wh_scale must be the folded value. */
 int32_t vcnf_rqs_layer_fused_tile_rows(void);
+/* F16X3 path: batches of up to `rows` samples run on 32-sample tiles (one workgroup per 32
+ * samples: the batch sizes of the reference's drivers, /root/reference/run.py:45-47, fill the
+ * chip), larger ones on 128-sample tiles.  Same results contract; y is bitwise the same on
+ * both, logdet differs by the order of its per-sample sum.  Process-wide; rows < 0 only
+ * queries.  Returns the previous value (default 16384). */
+int64_t vcnf_rqs_layer_fused_small_batch_rows(int64_t rows);
 int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, float* logdet,
                              int64_t batch, const int32_t* transform_idx, int32_t d_t,
                              const int32_t* identity_idx, int32_t d_id, int32_t ctx_dim,

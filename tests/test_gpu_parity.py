@@ -38,10 +38,26 @@ def load(module, sd, fused=True):
     return set_fused(module.cuda().eval(), fused)
 
 
+SMALL_BATCH_ROWS_DEFAULT = 16384
+
+
+@pytest.fixture(autouse=True)
+def _default_tile_threshold():
+    """set_fused(..., "fp16x3-t128") moves the process-wide small-batch threshold of the fused RQS layer; every test
+    starts and ends on the default."""
+    yield
+    if torch.cuda.is_available():
+        _lib.small_batch_rows(SMALL_BATCH_ROWS_DEFAULT)
+
+
 def set_fused(module, flag):
     """Route eligible RQS couplings through the single-kernel layer - "fp16x3" (split-half
-    fp16 matrix path, the default) or "fp32" (exact fp32 matrix path) - or, with False,
-    through the gather kernel + torch GEMMs + spline kernel."""
+    fp16 matrix path, the default; at these batch sizes the 32-sample-tile kernel, csrc/fused_layer_v6s.hip),
+    "fp16x3-t128" (the same path forced onto the 128-sample-tile kernel of large batches, csrc/fused_layer_v6.hip)
+    or "fp32" (exact fp32 matrix path) - or, with False, through the gather kernel + torch GEMMs + spline kernel."""
+    if isinstance(flag, str) and flag.startswith("fp16x3"):
+        _lib.small_batch_rows(0 if flag == "fp16x3-t128" else SMALL_BATCH_ROWS_DEFAULT)
+        flag = "fp16x3"
     for m in module.modules():
         if isinstance(m, nf.flows.PiecewiseRationalQuadraticCoupling):
             m.fused = bool(flag)
@@ -49,7 +65,8 @@ def set_fused(module, flag):
     return module
 
 
-FUSED = pytest.mark.parametrize("fused", ["fp16x3", "fp32", False], ids=["fused-fp16x3", "fused-fp32", "split"])
+FUSED = pytest.mark.parametrize("fused", ["fp16x3", "fp16x3-t128", "fp32", False],
+                                ids=["fused-fp16x3", "fused-fp16x3-t128", "fused-fp32", "split"])
 
 
 # ---------------------------------------------------------------- splines (G1, G2)
@@ -836,22 +853,25 @@ def test_fp16x3_saturation_is_counted_and_fp32_restores_parity(hip):
     assert float((ld16.cpu() - ldo).abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("tile", [32, 128])
 @pytest.mark.parametrize("blocks", [1, 2, 3])
 @pytest.mark.parametrize("sampling", [False, True], ids=["density", "sampling"])
-def test_fp16x3_default_is_range_safe_on_the_device(hip, blocks, sampling):
-    """The DEFAULT matrix path (fp16 split-half operands) never clamps: a 128-sample tile that holds a value the fp16
+def test_fp16x3_default_is_range_safe_on_the_device(hip, blocks, sampling, tile):
+    """The DEFAULT matrix path (fp16 split-half operands) never clamps: a tile (32 samples in the small-batch kernel,
+    128 in the large-batch one) that holds a value the fp16
     halves cannot carry - a hidden activation beyond +-65504, a huge input, a NaN / Inf input - is left unwritten by the
     split-half kernel and evaluated by the exact fp32 kernel in the launch behind it, without a host round trip.
     Asserted: those tiles are BITWISE the exact fp32 path's results (non-finite patterns included), every other tile
     is BITWISE the split-half path's own result on clean inputs, the redo counter says which is which, and both
     log_det modes (store / accumulate into a running log_q) honour the skip."""
     torch.manual_seed(40 + blocks)
-    m = set_fused(nf.flows.CoupledRationalQuadraticSpline(64, blocks, 128, 8, num_context_channels=16).cuda().eval(), "fp16x3")
+    mode = "fp16x3" if tile == 32 else "fp16x3-t128"
+    m = set_fused(nf.flows.CoupledRationalQuadraticSpline(64, blocks, 128, 8, num_context_channels=16).cuda().eval(), mode)
     with torch.no_grad():
         for n, p in m.named_parameters():
             if "unnormalized_" in n:
                 p.normal_(0.0, 0.5)
-    B = 128 * 5 + 37                                       # six tiles, the last one ragged
+    B = 128 * 5 + 37                                       # six tiles of 128, the last one ragged
     x = torch.randn(B, 64, device="cuda")
     ctx = torch.randn(B, 16, device="cuda")
     call = (lambda mod, a, c: mod.forward(a, context=c)) if sampling else (lambda mod, a, c: mod.inverse(a, context=c))
@@ -865,18 +885,18 @@ def test_fp16x3_default_is_range_safe_on_the_device(hip, blocks, sampling):
     cb[300, 5] = float("inf")             # tile 2: non-finite context
     xb[128 * 4 + 7, idf[0]] = float("nan")    # tile 4: NaN conditioner input
     xb[10, tff[2]] = 1.0e6                # tile 0: a TRANSFORMED feature may be anything (it never enters a GEMM)
-    bad_tiles = [1, 2, 4]
+    bad_tiles = [130 // tile, 300 // tile, (128 * 4 + 7) // tile]
     with torch.no_grad():
         z, ld = call(m, xb, cb)
         assert nf.range_redo_count() == len(bad_tiles)
         m32 = set_fused(m, "fp32")
         z32, ld32 = call(m32, xb, cb)
-        set_fused(m, "fp16x3")
+        set_fused(m, mode)
         # accumulate mode: the running log_q of NormalizingFlow.log_prob / sample
         logq = torch.full((B,), 0.25, device="cuda")
         z_acc = m.forward_into(xb, logq, context=cb) if sampling else m.inverse_into(xb, logq, context=cb)
     torch.cuda.synchronize()
-    rows = torch.arange(B, device="cuda") // 128
+    rows = torch.arange(B, device="cuda") // tile
     redo = torch.isin(rows, torch.tensor(bad_tiles, device="cuda"))
     eq = lambda a, b: torch.equal(a, b) or torch.equal(torch.nan_to_num(a, nan=1.25e30), torch.nan_to_num(b, nan=1.25e30))
     assert eq(z[redo], z32[redo]) and eq(ld[redo], ld32[redo]), "flagged tiles must carry the exact fp32 kernel's results"
@@ -890,6 +910,42 @@ def test_fp16x3_default_is_range_safe_on_the_device(hip, blocks, sampling):
     assert eq(logq, 0.25 + sign * ld)
     nf.range_redo_count()
     _lib.bad_discriminant_counter("cuda").zero_()           # the NaN rows tripped the sampling direction's discriminant check
+
+
+@pytest.mark.parametrize("blocks", [1, 2, 3])
+@pytest.mark.parametrize("d,ctx_dim", [(64, 16), (64, 0), (32, 16), (32, 0)])
+def test_small_batch_kernel_matches_large_batch_kernel(hip, d, ctx_dim, blocks):
+    """csrc/fused_layer_v6s.hip (32-sample tiles, batches up to 16384) against csrc/fused_layer_v6.hip (128-sample
+    tiles): same packed weights, same matrix instructions in the same order - z must be BITWISE equal, log_det equal
+    up to the order of its per-sample sum; both directions, store and accumulate modes, ragged batches (1 row, a
+    partial last tile, more tiles than resident workgroups), with and without the unconditional identity spline."""
+    from vcnf_amd import fused as fz
+    torch.manual_seed(300 + d + ctx_dim + blocks)
+    m = nf.flows.CoupledRationalQuadraticSpline(d, blocks, 128, 8, num_context_channels=ctx_dim or None).cuda().eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "unnormalized_" in n:
+                p.normal_(0.0, 0.5)
+    assert fz.eligible(m.prqct, torch.zeros(1, ctx_dim, device="cuda") if ctx_dim else None)
+    for B in (1, 31, 32, 33, 2048 + 17, 32 * 256 + 45):
+        x = torch.randn(B, d, device="cuda") * 1.5
+        ctx = torch.randn(B, ctx_dim, device="cuda") if ctx_dim else None
+        kw = {"context": ctx} if ctx_dim else {}
+        out = {}
+        for mode in ("fp16x3", "fp16x3-t128"):
+            set_fused(m, mode)
+            with torch.no_grad():
+                zf, ldf = m.forward(x, **kw)
+                zi, ldi = m.inverse(x, **kw)
+                lq = torch.full((B,), -0.5, device="cuda")
+                za = m.inverse_into(x, lq, **kw)
+            out[mode] = (zf, ldf, zi, ldi, za, lq)
+        a, b = out["fp16x3"], out["fp16x3-t128"]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[4], b[4]), (B, "z differs")
+        for i in (1, 3, 5):
+            tol = 4e-6 * (1.0 + b[i].abs())
+            assert bool(((a[i] - b[i]).abs() <= tol).all()), (B, i, float((a[i] - b[i]).abs().max()))
+    nf.check_discriminant()
 
 
 def test_data_mutation_needs_refresh_packed(hip):

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "vcnf_rqs_layer_fused_pack_floats": ([_I32, _I32, _I32, _I32], _I64),
     "vcnf_rqs_layer_fused_supported": ([_I32, _I32, _I32, _I32, _I32, _I32, _I32], _INT),
     "vcnf_rqs_layer_fused_tile_rows": ([], _I32),
+    "vcnf_rqs_layer_fused_small_batch_rows": ([_I64], _I64),
     "vcnf_rqs_layer_fused_f32": ([_P, _P, _P, _P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _I64,
                                   _P, _P, _P, ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P, _P, _P], _INT),
     "vcnf_affine_coupling_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _INT, _INT,
@@ -544,6 +545,13 @@ def _redo_flags(dev, tiles):
     return buf
 
 
+def small_batch_rows(rows=None):
+    """Batch size up to which the fp16 split-half fused RQS layer runs on 32-sample tiles (csrc/fused_layer_v6s.hip)
+    instead of 128-sample ones; ``rows`` sets it (0: never, a huge value: always), None only queries.  Returns the
+    previous value.  Process-wide."""
+    return int(lib().vcnf_rqs_layer_fused_small_batch_rows(-1 if rows is None else int(rows)))
+
+
 def rqs_layer_fused(x, context, tf_idx, id_idx, ctx_dim, hidden, num_blocks, precision, wpack, shared, cfg,
                     inverse, logdet=None, sign=1.0, wpack_f32=None, cfg_f32=None):
     """Whole coupling layer (conditioner included) in one kernel; see csrc/fused_layer.hip.
@@ -574,7 +582,7 @@ def rqs_layer_fused(x, context, tf_idx, id_idx, ctx_dim, hidden, num_blocks, pre
                                           ctypes.byref(cf), int(bool(inverse)), mode, float(sign),
                                           _ptr(bad_discriminant_counter(dev)) if inverse else None, sat, redo, _stream())
     with torch.cuda.device(dev):
-        flags = _redo_flags(dev, (b + 127) // 128) if safe and b > 0 else None
+        flags = _redo_flags(dev, (b + 31) // 32) if safe and b > 0 else None        # one flag per 32 samples
         if sink is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()

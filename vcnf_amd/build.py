@@ -19,6 +19,7 @@ SOURCES = ["rqs_kernels.hip", "affine_kernels.hip", "fused_layer.hip",
 NO_SLP = ["-fno-slp-vectorize"]
 UNITS = [(s, NO_SLP if s == "fused_final.hip" else [], os.path.splitext(s)[0]) for s in SOURCES if s != "fused_layer_v6.hip"] + \
         [("fused_layer_v6.hip", ["-DVCNF_V6_NBLK=%d" % n] + NO_SLP, "fused_layer_v6_b%d" % n) for n in (2, 3, 1)] + \
+        [("fused_layer_v6s.hip", ["-DVCNF_V6_NBLK=%d" % n] + NO_SLP, "fused_layer_v6s_b%d" % n) for n in (2, 3, 1)] + \
         [("fused_layer.hip", ["-DVCNF_F32_NBLK=%d" % n], "fused_layer_f32_b%d" % n) for n in (3, 1)]
 HEADERS = ["rqs_math.hpp", "rqs_lean.hpp", "fused_common.hpp", "split_half.hpp", os.path.join("..", "..", "include", "vcnf_hip.h")]
 
@@ -27,7 +28,7 @@ def stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + ["fused_layer_v6s.hip"] + HEADERS)
 
 
 def build(force=False, verbose=False):

@@ -11,7 +11,8 @@ namespace vcnf {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int kFBlock = 256;     // 4 waves; each wave owns kCB 16-sample column blocks of the tile
-constexpr int kFusedTile = 128;  // samples per tile of BOTH fused layer kernels (the redo flags are per tile)
+constexpr int kFusedTile = 128;  // samples per tile of the large-batch fused layer kernels
+constexpr int kFusedFlagRows = 32;   // samples per range flag (FusedArgs::redo) = tile of the small-batch kernel
 
 struct FusedArgs {
   const float* x;
@@ -25,9 +26,10 @@ struct FusedArgs {
   unsigned wpack_bytes;
   int32_t* bad;
   int32_t* sat;                          // fp16 split-half path: tiles with a value beyond the fp16 range (or NULL)
-  int32_t* redo;                         // [tiles of kFusedTile rows] or NULL.  Split-half kernel: OUT - 1 for a tile that
-                                         // held a non-finite input or a value beyond +-65504 (nothing of that tile is
-                                         // written), else 0.  Exact fp32 kernel: IN - only flagged tiles are evaluated.
+  int32_t* redo;                         // [ceil(B / kFusedFlagRows)] or NULL.  Split-half kernels: OUT - 1 for the rows
+                                         // of a tile that held a non-finite input or a value beyond +-65504 (nothing of
+                                         // that tile is written; a 128-sample tile sets its four entries), else 0.
+                                         // Exact fp32 kernel: IN - only flagged rows are evaluated and written.
   long long B;
   int ld_mode;
   float ld_sign;
@@ -149,5 +151,10 @@ int launch_fused_f32_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, 
 int launch_fused_v6_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
 int launch_fused_v6_b2(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
 int launch_fused_v6_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
+
+// defined in fused_layer_v6s.hip (32-sample tiles: small batches)
+int launch_fused_v6s_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
+int launch_fused_v6s_b2(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
+int launch_fused_v6s_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
 
 }  // namespace vcnf

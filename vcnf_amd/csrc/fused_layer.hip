@@ -64,7 +64,7 @@ __device__ __forceinline__ void bias_block(__amdgpu_buffer_rsrc_t rsrc, int qoff
 template <int DI, int DT, int C, int H, int NBLK, int K, bool INV, int kCB>
 __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const FusedArgs a) {
   constexpr int kTile = 4 * kCB * 16;       // samples per workgroup tile
-  static_assert(kTile == kFusedTile, "the redo flags of the split-half kernel are per 128-sample tile");
+  static_assert(kTile == kFusedTile && kTile == 4 * kFusedFlagRows, "one tile = four 32-sample range flags");
   constexpr int D = DI + DT;
   constexpr int XS = D + 4;                 // padded LDS row strides (16-byte aligned rows)
   constexpr int CS = (C > 0 ? C : 4) + 4;
@@ -96,18 +96,21 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
   if (a.redo) {
     // re-evaluation pass behind the split-half kernel: normally no tile is flagged - leave before any set-up
     // (index tables, knot tables) so that the launch costs a few microseconds
-    const long long nt = (a.B + kTile - 1) / kTile;
+    const long long nt = (a.B + kTile - 1) / kTile, nf = (a.B + kFusedFlagRows - 1) / kFusedFlagRows;
     int any = 0;
-    for (long long t = blockIdx.x; t < nt; t += gridDim.x) any |= a.redo[t];
+    for (long long t = blockIdx.x; t < nt; t += gridDim.x)
+      for (int k = 0; k < 4; ++k) any |= 4 * t + k < nf ? a.redo[4 * t + k] : 0;
     if (!any) return;
   }
 
   for (int i = tid; i < DT; i += kFBlock) tfi[i] = a.tf_idx[i];
   for (int i = tid; i < DI; i += kFBlock) idi[i] = a.id_idx[i];
   if (shared) {
-    for (int f = tid; f < DI; f += kFBlock) {
+    // knot tables of the identity half: one thread per (feature, column: x knots | y knots | derivatives)
+    for (int i = tid; i < 3 * DI; i += kFBlock) {
+      const int f = i % DI;
       SplitLogits p{a.sh_w + f * K, a.sh_h + f * K, a.sh_d + f * (K - 1), K, 1.f, c.edge_logit, c.tails};
-      rqs_build_table(p, c, tab + f * TABW);
+      rqs_build_table_part_k<K>(p, c, tab + f * TABW, 1, i / DI);
     }
   }
 
@@ -115,9 +118,16 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
   bool bad = false;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // re-evaluation pass behind the split-half kernel: only the tiles it flagged (and did not write)
-    if (a.redo && a.redo[tile] == 0) continue;
+    // (one flag per 32 rows: a flagged quarter is written, the others are left as the split-half kernel wrote them)
     const long long b0 = tile * kTile;
     const int rows = (int)min((long long)kTile, a.B - b0);
+    unsigned wmask = 0xFu;
+    if (a.redo) {
+      wmask = 0u;
+      for (int k = 0; k < 4; ++k)
+        if (k * kFusedFlagRows < rows && a.redo[4 * tile + k] != 0) wmask |= 1u << k;
+      if (wmask == 0u) continue;
+    }
     __syncthreads();
     // ---- stage x rows and context rows (coalesced 16-byte loads, padded LDS rows)
     {
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
       const int m = (wave * kCB + cb) * 16 + m16;
-      if (q == 0 && m < rows) {
+      if (q == 0 && m < rows && ((wmask >> (m / kFusedFlagRows)) & 1u)) {
         const float o = a.ld_sign * v;
         a.logdet[b0 + m] = a.ld_mode ? a.logdet[b0 + m] + o : o;
       }
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
       float4* dst = reinterpret_cast<float4*>(a.y) + b0 * D4;
       for (int i = tid; i < rows * D4; i += kFBlock) {
         const int r = i / D4, o = i - r * D4;
-        dst[i] = *reinterpret_cast<const float4*>(xt + r * XS + 4 * o);
+        if ((wmask >> (r / kFusedFlagRows)) & 1u) dst[i] = *reinterpret_cast<const float4*>(xt + r * XS + 4 * o);
       }
     }
   }
@@ -355,7 +365,7 @@ extern "C" int64_t vcnf_rqs_layer_fused_pack_floats(int32_t d_id, int32_t d_t, i
   }
 }
 
-extern "C" int32_t vcnf_rqs_layer_fused_tile_rows(void) { return kFusedTile; }
+extern "C" int32_t vcnf_rqs_layer_fused_tile_rows(void) { return kFusedFlagRows; }
 
 extern "C" int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t ctx_dim, int32_t hidden,
                                               int32_t num_blocks, int32_t num_bins, int32_t tails) {
@@ -366,7 +376,23 @@ extern "C" int vcnf_rqs_layer_fused_supported(int32_t d_id, int32_t d_t, int32_t
 // fp16 split-half matrix path: fused_layer_v6.hip, one translation unit per number of residual blocks.
 // (Earlier structures v2 - v6 are kept as text under profiles/tools/superseded/; they are no longer part
 // of the library.)
+// Batches up to this many samples take the 32-sample-tile kernel (fused_layer_v6s.hip): below it the 128-sample
+// kernel leaves most of the chip idle (2048 samples = 16 workgroups), above it (>= 256 tiles of 128) its
+// wave-group overlap wins.  Process-wide, set by vcnf_rqs_layer_fused_small_batch_rows().
+static long long g_small_batch_rows = 16384;
+
+extern "C" int64_t vcnf_rqs_layer_fused_small_batch_rows(int64_t rows) {
+  const long long prev = g_small_batch_rows;
+  if (rows >= 0) g_small_batch_rows = rows;
+  return prev;
+}
+
 static int launch_f16x3(const FusedArgs& a, int d_id, int ctx_dim, int num_blocks, int inverse, hipStream_t st) {
+  if (a.B <= g_small_batch_rows) {
+    if (num_blocks == 1) return launch_fused_v6s_b1(a, d_id, ctx_dim, inverse, st);
+    if (num_blocks == 2) return launch_fused_v6s_b2(a, d_id, ctx_dim, inverse, st);
+    return launch_fused_v6s_b3(a, d_id, ctx_dim, inverse, st);
+  }
   if (num_blocks == 1) return launch_fused_v6_b1(a, d_id, ctx_dim, inverse, st);
   if (num_blocks == 2) return launch_fused_v6_b2(a, d_id, ctx_dim, inverse, st);
   return launch_fused_v6_b3(a, d_id, ctx_dim, inverse, st);

@@ -131,9 +131,11 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6_kernel(const FusedA
   for (int i = tid; i < DT; i += kBlock) tfi[i] = a.tf_idx[i];
   for (int i = tid; i < DI; i += kBlock) idi[i] = a.id_idx[i];
   if (shared) {
-    for (int f = tid; f < DI; f += kBlock) {
+    // knot tables of the identity half: one thread per (feature, column: x knots | y knots | derivatives)
+    for (int i = tid; i < 3 * DI; i += kBlock) {
+      const int f = i % DI;
       SplitLogits p{a.sh_w + f * K, a.sh_h + f * K, a.sh_d + f * (K - 1), K, 1.f, c.edge_logit, c.tails};
-      rqs_build_table(p, c, tab + f * TABW);
+      rqs_build_table_part_k<K>(p, c, tab + f * TABW, 1, i / DI);
     }
   }
 
@@ -574,10 +576,9 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6_kernel(const FusedA
     // gave a flag array: the exact fp32 kernel evaluates it from the untouched inputs (vcnf_rqs_layer_fused_f32,
     // redo_tiles).  Without the array the clamped results are stored and only counted (sat).
     const bool over = *tflag != 0;
-    if (tid == 0) {
-      if (a.redo) a.redo[tile] = over ? 1 : 0;
-      if (over && a.sat) atomicAdd(a.sat, 1);
-    }
+    if (tid == 0 && over && a.sat) atomicAdd(a.sat, 1);
+    if (a.redo && tid < kTile / kFusedFlagRows && b0 + tid * kFusedFlagRows < a.B)   // one flag per 32 rows
+      a.redo[tile * (kTile / kFusedFlagRows) + tid] = over ? 1 : 0;
     if (over && a.redo) continue;
     if (ch == 0 && kg == 0) {
       const int mrow = rp * 32 + c32;

@@ -329,6 +329,46 @@ __device__ __forceinline__ void rqs_build_table_part(const P& p, const RqsConst&
   }
 }
 
+// rqs_build_table_part with the bin count known at compile time: the column's logits are fetched first (independent
+// loads: ONE memory latency - the run-time loops above wait for a load in every iteration, 7 us per workgroup
+// measured in the fused layer kernels, profiles/r03_small_batch.md), then the same operations in the same order:
+// bitwise the same table.
+template <int K, class P>
+__device__ __forceinline__ void rqs_build_table_part_k(const P& p, const RqsConst& c, float* tab, int stride, int part) {
+  float* col = tab + part * (K + 1) * stride;
+  if (part == 2) {
+    float d[K + 1];
+#pragma unroll
+    for (int k = 0; k <= K; ++k) d[k] = p.d(k);
+#pragma unroll
+    for (int k = 0; k <= K; ++k) col[k * stride] = c.min_d + softplus_f(d[k]);
+    return;
+  }
+  const bool xs = part == 0;
+  float v[K], e[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = xs ? p.w(k) : p.h(k);
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < K; ++k) m = fmaxf(m, v[k]);
+  const float sc2 = p.scale * kLog2e;
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    e[k] = hw_exp2((v[k] - m) * sc2);
+    sum += e[k];
+  }
+  const float g = div_nr(xs ? c.free_w : c.free_h, sum);
+  const float mn = xs ? c.min_w : c.min_h, span = xs ? c.span_x : c.span_y, lo = xs ? c.lo_x : c.lo_y;
+  float cum = 0.f;
+  col[0] = lo;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    cum += fmaf(e[k], g, mn);
+    col[(k + 1) * stride] = (k == K - 1) ? (xs ? c.hi_x : c.hi_y) : fmaf(span, cum, lo);
+  }
+}
+
 template <class P>
 __device__ __forceinline__ void rqs_build_table(const P& p, const RqsConst& c, float* tab, int stride = 1) {
 #pragma unroll 1
