@@ -370,6 +370,34 @@ int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, flo
                              int ld_mode, float ld_sign, int32_t* bad_disc, int32_t* sat_count,
                              int32_t* redo_tiles, void* stream);
 
+/* A run of n_layers (<= vcnf_rqs_stack_fused_max_layers() = 16) RQS coupling layers of ONE shape and one spline
+ * configuration in a single launch: the body of NormalizingFlow.log_prob / sample over consecutive
+ * CoupledRationalQuadraticSpline layers (core.py:144-183 around coupling.py:70-125).  `layers` is a HOST array in
+ * the order in which the layers are applied to x (its entries are copied into the launch); every entry carries the
+ * layer's index vectors, its packed conditioner weights for `precision` and the unconditional spline's logits
+ * (all layers with them, or none).  y = the last layer's output; logdet receives / accumulates ld_sign * the SUM of
+ * the layers' log|det| (one rounding of the sum instead of one per layer).  Everything else as
+ * vcnf_rqs_layer_fused_f32.  F16X3: every layer runs on 32-sample tiles that stay in LDS from the first layer to
+ * the last (meant for the small batches at which one launch per layer is launch-bound: the reference's drivers use
+ * 1024 - 2048 samples, /root/reference/run.py:45-47); a tile in which ANY layer met a value the fp16 halves cannot
+ * carry is left unwritten and flagged in redo_tiles, and the same call with VCNF_PREC_F32 and the F32 packings
+ * evaluates exactly the flagged rows through all layers on exact fp32 matrix instructions. */
+typedef struct vcnf_rqs_stack_layer {
+  const int32_t* transform_idx;
+  const int32_t* identity_idx;
+  const float* wpack;
+  const float* shared_w;
+  const float* shared_h;
+  const float* shared_d;
+} vcnf_rqs_stack_layer;
+int32_t vcnf_rqs_stack_fused_max_layers(void);
+int vcnf_rqs_stack_fused_f32(const float* x, const float* context, float* y, float* logdet,
+                             int64_t batch, const vcnf_rqs_stack_layer* layers, int32_t n_layers,
+                             int32_t d_t, int32_t d_id, int32_t ctx_dim, int32_t hidden,
+                             int32_t num_blocks, int32_t precision, int64_t wpack_floats,
+                             const vcnf_rqs_cfg* cfg, int inverse, int ld_mode, float ld_sign,
+                             int32_t* bad_disc, int32_t* sat_count, int32_t* redo_tiles, void* stream);
+
 /* Affine coupling on z[B, C, inner] (inner = H*W, 1 for 2-D inputs).
  * Replaces AffineCoupling.forward / .inverse (flows/affine/coupling.py:113-142 /
  * :144-168) together with the channel Split / Merge around it

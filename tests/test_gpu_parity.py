@@ -948,6 +948,105 @@ def test_small_batch_kernel_matches_large_batch_kernel(hip, d, ctx_dim, blocks):
     nf.check_discriminant()
 
 
+@pytest.mark.parametrize("precision", ["fp16x3", "fp32"])
+@pytest.mark.parametrize("layers,d,ctx_dim,blocks", [(12, 64, 16, 2), (5, 32, 0, 1), (16, 64, 16, 3), (19, 64, 16, 2)])
+def test_rqs_stack_single_launch_matches_per_layer(hip, layers, d, ctx_dim, blocks, precision):
+    """NormalizingFlow evaluates a run of one-kernel RQS layers at a small batch in ONE launch
+    (vcnf_rqs_stack_fused_f32: the tile stays in LDS from the first layer to the last; 19 layers = a run of 16 and a
+    run of 3).  Against one launch per layer (``fuse_rqs_stacks = False``): samples BITWISE equal, log-densities equal
+    up to the rounding of one sum over the layers instead of one add per layer; both directions, both matrix paths,
+    ragged batches."""
+    torch.manual_seed(700 + layers + d)
+    model = set_fused(_c3_model(layers=layers, d=d, c=ctx_dim or None, blocks=blocks).cuda().eval(), precision)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "unnormalized_" in n:
+                p.normal_(0.0, 0.5)
+    from vcnf_amd import fused as fz
+    for B in (1, 33, 1024 + 7):
+        x, eps = torch.randn(B, d, device="cuda") * 1.3, torch.randn(B, d, device="cuda")
+        ctx = torch.randn(B, ctx_dim, device="cuda") if ctx_dim else None
+        kw = {"context": ctx} if ctx_dim else {}
+        with torch.no_grad():
+            assert fz.plan_stack(list(model.flows), 0, x, ctx) is not None
+        out = {}
+        for stacks in (True, False):
+            model.fuse_rqs_stacks = stacks
+            with torch.no_grad():
+                lp = model.log_prob(x, **kw)
+                z, lq = model.sample_from(eps, **kw)
+                # the density direction's latents: the run itself, outside log_prob
+                zi, lqi = x, torch.zeros(B, device="cuda")
+                if stacks:
+                    order, i = list(reversed(model.flows)), 0
+                    while i < len(order):
+                        end, run, sig = fz.plan_stack(order, i, zi, ctx) or (i + 1, None, None)
+                        zi = (fz.run_stack(run, sig, zi, ctx, False, lqi, 1.0)[0] if run else order[i].inverse_into(zi, lqi, **kw))
+                        i = end
+                else:
+                    for f in reversed(model.flows):
+                        zi = f.inverse_into(zi, lqi, **kw)
+            out[stacks] = (lp, z, lq, zi, lqi)
+        model.fuse_rqs_stacks = True
+        a, b = out[True], out[False]
+        assert torch.equal(a[1], b[1]) and torch.equal(a[3], b[3]), (B, "latents differ")
+        for i in (0, 2, 4):
+            # the running log-density passes through magnitudes of ~1e2 (base density, D = 64): one rounding per layer
+            # there (ulp 7.6e-6) against one for the whole run
+            assert bool(((a[i] - b[i]).abs() <= 1e-4).all()), (B, i, float((a[i] - b[i]).abs().max()))
+    nf.check_discriminant()
+
+
+@pytest.mark.parametrize("sampling", [False, True], ids=["density", "sampling"])
+def test_rqs_stack_is_range_safe_on_the_device(hip, sampling):
+    """Range safety of the single-launch run on the split-half path: a 32-sample tile in which ANY layer met a value the
+    fp16 halves cannot carry (here: a huge identity-feature input, a non-finite context entry, a NaN input) is left
+    unwritten and re-evaluated through ALL layers by the exact fp32 kernel in the launch behind - those rows are BITWISE
+    the fp32 model's latents (log-density: to the order of the sum), every other row BITWISE the clean run's, the redo
+    counter counts the flagged tiles."""
+    torch.manual_seed(77)
+    model = set_fused(_c3_model(layers=6).cuda().eval(), "fp16x3")
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "unnormalized_" in n:
+                p.normal_(0.0, 0.5)
+    B = 32 * 9 + 5
+    x, ctx = torch.randn(B, 64, device="cuda"), torch.randn(B, 16, device="cuda")
+
+    def run(m, xa, ca):
+        with torch.no_grad():
+            if sampling:
+                return m.sample_from(xa, context=ca)
+            lq = torch.zeros(B, device="cuda")
+            from vcnf_amd import fused as fz
+            order = list(reversed(m.flows))
+            plan = fz.plan_stack(order, 0, xa, ca)
+            assert plan is not None and plan[0] == len(order)
+            return fz.run_stack(plan[1], plan[2], xa, ca, False, lq, 1.0)[0], lq
+    nf.range_redo_count()
+    z_clean, lq_clean = run(model, x, ctx)
+    assert nf.range_redo_count() == 0
+    first = (model.flows[0] if sampling else model.flows[-1]).prqct       # the layer applied first
+    idf = first.identity_features.tolist()
+    xb, cb = x.clone(), ctx.clone()
+    xb[40, idf[3]] = 3.0e5
+    cb[100, 5] = float("inf")
+    xb[32 * 9 + 2, idf[0]] = float("nan")
+    bad_tiles = [40 // 32, 100 // 32, 9]
+    z, lq = run(model, xb, cb)
+    assert nf.range_redo_count() == len(bad_tiles)
+    z32, lq32 = run(set_fused(model, "fp32"), xb, cb)
+    set_fused(model, "fp16x3")
+    torch.cuda.synchronize()
+    rows = torch.arange(B, device="cuda") // 32
+    redo = torch.isin(rows, torch.tensor(bad_tiles, device="cuda"))
+    eq = lambda a, b: torch.equal(torch.nan_to_num(a, nan=1.25e30), torch.nan_to_num(b, nan=1.25e30))
+    assert eq(z[redo], z32[redo]) and eq(lq[redo], lq32[redo]), "flagged tiles must carry the exact fp32 kernel's results"
+    assert torch.equal(z[~redo], z_clean[~redo]) and torch.equal(lq[~redo], lq_clean[~redo])
+    nf.range_redo_count()
+    _lib.bad_discriminant_counter("cuda").zero_()
+
+
 def test_data_mutation_needs_refresh_packed(hip):
     """the packed weight caches key on (data_ptr, _version); ``p.data`` edits do not bump _version.
     refresh_packed() (also run by train() / eval() / load_state_dict()) makes the fused kernel see them."""

@@ -38,6 +38,12 @@ class RqsCfg64(ctypes.Structure):
                 ("min_bin_height", _F64), ("min_derivative", _F64), ("wh_scale", _F64)]
 
 
+class RqsStackLayer(ctypes.Structure):
+    """struct vcnf_rqs_stack_layer"""
+    _fields_ = [("transform_idx", ctypes.c_void_p), ("identity_idx", ctypes.c_void_p), ("wpack", ctypes.c_void_p),
+                ("shared_w", ctypes.c_void_p), ("shared_h", ctypes.c_void_p), ("shared_d", ctypes.c_void_p)]
+
+
 # name -> argtypes, exactly the prototypes of include/vcnf_hip.h
 PROTOTYPES = {
     "vcnf_abi_version": ([], _INT),
@@ -92,6 +98,9 @@ PROTOTYPES = {
     "vcnf_rqs_layer_fused_supported": ([_I32, _I32, _I32, _I32, _I32, _I32, _I32], _INT),
     "vcnf_rqs_layer_fused_tile_rows": ([], _I32),
     "vcnf_rqs_layer_fused_small_batch_rows": ([_I64], _I64),
+    "vcnf_rqs_stack_fused_max_layers": ([], _I32),
+    "vcnf_rqs_stack_fused_f32": ([_P, _P, _P, _P, _I64, ctypes.POINTER(RqsStackLayer), _I32, _I32, _I32, _I32, _I32, _I32,
+                                  _I32, _I64, ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P, _P, _P], _INT),
     "vcnf_rqs_layer_fused_f32": ([_P, _P, _P, _P, _I64, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _I64,
                                   _P, _P, _P, ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P, _P, _P], _INT),
     "vcnf_affine_coupling_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _INT, _INT,
@@ -170,7 +179,9 @@ def _check(status, what):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw handle of the current stream of the current device (torch.cuda.current_stream() builds a Stream object
+    # and resolves the device through three layers of helpers: 8 us per call, several calls per layer)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def _ptr(t):
@@ -594,6 +605,47 @@ def rqs_layer_fused(x, context, tf_idx, id_idx, ctx_dim, hidden, num_blocks, pre
         if st == OK and flags is not None:
             st = launch(0, wpack_f32, cfg_f32 if cfg_f32 is not None else cfg, None, _ptr(flags))
     _check(st, "vcnf_rqs_layer_fused_f32")
+    return y, logdet
+
+
+def rqs_stack_fused(x, context, layers, layers_f32, pack_floats, d_t, d_id, ctx_dim, hidden, num_blocks, precision, cfg,
+                    inverse, logdet=None, sign=1.0):
+    """A run of RQS coupling layers of one shape in ONE launch (csrc/fused_layer_v6s.hip; exact fp32:
+    csrc/fused_layer.hip): ``layers`` is a ctypes array of RqsStackLayer in application order.  precision 1 with
+    ``layers_f32`` (the same layers with their fp32 packings) is the range-safe pair of launches of rqs_layer_fused:
+    tiles in which any layer left the fp16 range are re-evaluated through all layers on exact fp32 instructions."""
+    dev = require_device(x, context, logdet)
+    b = x.shape[0]
+    x = x.contiguous()
+    if context is not None:
+        context = context.contiguous()
+    y = torch.empty_like(x)
+    mode = LD_ACCUM
+    if logdet is None:
+        logdet = torch.empty(b, dtype=torch.float32, device=dev)
+        mode = LD_STORE
+    L = lib()
+    safe = precision == 1 and layers_f32 is not None
+
+    def launch(prec, lay, sat, redo):
+        return L.vcnf_rqs_stack_fused_f32(_ptr(x), _ptr(context), _ptr(y), _ptr(logdet), b, lay, len(lay),
+                                          int(d_t), int(d_id), int(ctx_dim), int(hidden), int(num_blocks), int(prec),
+                                          int(pack_floats), ctypes.byref(cfg), int(bool(inverse)), mode, float(sign),
+                                          _ptr(bad_discriminant_counter(dev)) if inverse else None, sat, redo, _stream())
+    with torch.cuda.device(dev):
+        flags = _redo_flags(dev, (b + 31) // 32) if safe and b > 0 else None
+        sink = EVENT_SINK
+        if sink is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        st = launch(precision, layers, _ptr(range_redo_counter(dev) if safe else saturation_counter(dev)) if precision == 1 else None,
+                    _ptr(flags))
+        if sink is not None:
+            ev1.record()
+            sink.append((ev0, ev1, b))
+        if st == OK and flags is not None:
+            st = launch(0, layers_f32, None, _ptr(flags))
+    _check(st, "vcnf_rqs_stack_fused_f32")
     return y, logdet
 
 

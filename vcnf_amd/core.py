@@ -17,8 +17,9 @@ import torch
 from torch import nn
 
 from .flows.affine.coupling import AffineCouplingBlock, _scale_code
-from . import fused_affine
+from . import fused_affine, fused
 from .flows.mixing import Permute
+from .flows.neural_spline.wrapper import CoupledRationalQuadraticSpline
 from .fused import refresh_packed
 
 
@@ -49,6 +50,7 @@ class NormalizingFlow(_PackedWeightsMixin, nn.Module):
         self.p = p
         self.categoricals = None
         self.fuse_affine_stacks = True           # runs of one-kernel affine layers in a single launch (fused_affine.run_stack)
+        self.fuse_rqs_stacks = True              # runs of one-kernel RQS layers in a single launch at small batches (fused.run_stack)
 
     # ------------------------------------------------------------ density
     def log_prob(self, x, context=None):
@@ -74,6 +76,13 @@ class NormalizingFlow(_PackedWeightsMixin, nn.Module):
                     core_ = steps[0][0].flows[1]
                     z = fused_affine.run_stack(steps, trailing, z, _scale_code(core_.scale, core_.scale_map), True,
                                                log_q, 1.0)[0]
+                    continue
+            # a run of one-kernel RQS coupling layers at a small batch is ONE launch (the tile stays in LDS)
+            if self.fuse_rqs_stacks and type(flow) is CoupledRationalQuadraticSpline:
+                plan = fused.plan_stack(order, i, z, context)
+                if plan is not None:
+                    resume, run, sig = plan
+                    z = fused.run_stack(run, sig, z, context, False, log_q, 1.0)[0]
                     continue
             # a Permute undone right before a one-kernel affine layer becomes that kernel's load index
             if (isinstance(flow, Permute) and i + 1 < len(order) and z.dim() == 2
@@ -121,6 +130,12 @@ class NormalizingFlow(_PackedWeightsMixin, nn.Module):
                     core_ = steps[0][0].flows[1]
                     z = fused_affine.run_stack(steps, trailing, z, _scale_code(core_.scale, core_.scale_map), False,
                                                log_q, -1.0)[0]
+                    continue
+            if self.fuse_rqs_stacks and type(flow) is CoupledRationalQuadraticSpline:
+                plan = fused.plan_stack(order, i, z, context)
+                if plan is not None:
+                    resume, run, sig = plan
+                    z = fused.run_stack(run, sig, z, context, True, log_q, -1.0)[0]
                     continue
             # a Permute applied right after a one-kernel affine layer becomes that kernel's store index
             if (isinstance(flow, AffineCouplingBlock) and i + 1 < len(order) and isinstance(order[i + 1], Permute)

@@ -36,6 +36,22 @@ struct FusedArgs {
   RqsConst c;
 };
 
+// A run of coupling layers of ONE shape evaluated by one launch (small batches: the tile stays in LDS from the first
+// layer to the last, reference loop: normflow/core.py:144-183).  Per layer: index vectors, the unconditional
+// spline's logits, the packed conditioner weights.  FusedArgs::tf_idx / id_idx / sh_* / wpack are those of layer 0.
+constexpr int kMaxStackLayers = 16;
+struct FusedLayerDesc {
+  const int32_t* tf_idx;
+  const int32_t* id_idx;
+  const float *sh_w, *sh_h, *sh_d;
+  const float* wpack;
+};
+struct FusedStackArgs {
+  FusedArgs a;
+  int n_layers;
+  FusedLayerDesc lay[kMaxStackLayers];
+};
+
 __device__ __forceinline__ floatx4 mfma4(float a, float b, floatx4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -144,8 +160,8 @@ struct PackLayout6 {
 };
 
 // defined in fused_layer.hip built with -DVCNF_F32_NBLK=1 / 3 (exact fp32 kernel, one / three residual blocks)
-int launch_fused_f32_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
-int launch_fused_f32_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
+int launch_fused_f32_b1(const FusedStackArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
+int launch_fused_f32_b3(const FusedStackArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
 
 // defined in fused_layer_v6.hip
 int launch_fused_v6_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
@@ -153,8 +169,8 @@ int launch_fused_v6_b2(const FusedArgs& a, int d_id, int ctx_dim, int inverse, h
 int launch_fused_v6_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
 
 // defined in fused_layer_v6s.hip (32-sample tiles: small batches)
-int launch_fused_v6s_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
-int launch_fused_v6s_b2(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
-int launch_fused_v6s_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
+int launch_fused_v6s_b1(const FusedStackArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
+int launch_fused_v6s_b2(const FusedStackArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
+int launch_fused_v6s_b3(const FusedStackArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st);
 
 }  // namespace vcnf

@@ -62,7 +62,10 @@ __device__ __forceinline__ void bias_block(__amdgpu_buffer_rsrc_t rsrc, int qoff
 }
 
 template <int DI, int DT, int C, int H, int NBLK, int K, bool INV, int kCB>
-__global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const FusedStackArgs sa) {
+  // sa.n_layers coupling layers of one shape applied in order to each tile (1: the single-layer entry point); the
+  // tile stays in LDS between layers, log|det| is summed over the layers in registers (core.py:144-183)
+  const FusedArgs& a = sa.a;
   constexpr int kTile = 4 * kCB * 16;       // samples per workgroup tile
   static_assert(kTile == kFusedTile && kTile == 4 * kFusedFlagRows, "one tile = four 32-sample range flags");
   constexpr int D = DI + DT;
@@ -91,7 +94,8 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
   const int m16 = lane & 15;
   const int q = lane >> 4;
   const RqsConst& c = a.c;
-  const bool shared = a.sh_w != nullptr;
+  const bool shared = sa.lay[0].sh_w != nullptr;    // all layers of a stack or none
+  const int nlay = sa.n_layers;
 
   if (a.redo) {
     // re-evaluation pass behind the split-half kernel: normally no tile is flagged - leave before any set-up
@@ -103,19 +107,9 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
     if (!any) return;
   }
 
-  for (int i = tid; i < DT; i += kFBlock) tfi[i] = a.tf_idx[i];
-  for (int i = tid; i < DI; i += kFBlock) idi[i] = a.id_idx[i];
-  if (shared) {
-    // knot tables of the identity half: one thread per (feature, column: x knots | y knots | derivatives)
-    for (int i = tid; i < 3 * DI; i += kFBlock) {
-      const int f = i % DI;
-      SplitLogits p{a.sh_w + f * K, a.sh_h + f * K, a.sh_d + f * (K - 1), K, 1.f, c.edge_logit, c.tails};
-      rqs_build_table_part_k<K>(p, c, tab + f * TABW, 1, i / DI);
-    }
-  }
-
   const long long ntiles = (a.B + kTile - 1) / kTile;
   bool bad = false;
+  int have = -1;                            // layer whose index vectors / knot tables are in LDS
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // re-evaluation pass behind the split-half kernel: only the tiles it flagged (and did not write)
     // (one flag per 32 rows: a flagged quarter is written, the others are left as the split-half kernel wrote them)
@@ -150,6 +144,27 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
     }
     __syncthreads();
 
+    float ld_tot[kCB];
+#pragma unroll
+    for (int cb = 0; cb < kCB; ++cb) ld_tot[cb] = 0.f;
+   for (int l = 0; l < nlay; ++l) {
+    const FusedLayerDesc& lay = sa.lay[l];
+    if (have != l) {
+      // this layer's index vectors and knot tables (once per launch for a single layer)
+      if (have >= 0) __syncthreads();
+      for (int i = tid; i < DT; i += kFBlock) tfi[i] = lay.tf_idx[i];
+      for (int i = tid; i < DI; i += kFBlock) idi[i] = lay.id_idx[i];
+      if (shared) {
+        // knot tables of the identity half: one thread per (feature, column: x knots | y knots | derivatives)
+        for (int i = tid; i < 3 * DI; i += kFBlock) {
+          const int f = i % DI;
+          SplitLogits p{lay.sh_w + f * K, lay.sh_h + f * K, lay.sh_d + f * (K - 1), K, 1.f, c.edge_logit, c.tails};
+          rqs_build_table_part_k<K>(p, c, tab + f * TABW, 1, i / DI);
+        }
+      }
+      __syncthreads();
+      have = l;
+    }
     float ld_acc[kCB];
 #pragma unroll
     for (int cb = 0; cb < kCB; ++cb) ld_acc[cb] = 0.f;
@@ -194,7 +209,7 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
     using L = PackLayout<DI, DT, C, H, NBLK, K>;
     constexpr int NS0_4 = NS0 / 4, NSH_4 = NSH / 4, NSC_4 = (NSC > 0 ? NSC : 4) / 4;
     const __amdgpu_buffer_rsrc_t wr =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpack), 0, a.wpack_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lay.wpack), 0, a.wpack_bytes, 0x00020000);
     const int voff = lane * 16;       // fragment loads: 16 bytes per lane
     const int qoff = q * 16;          // bias loads: 4 consecutive rows per lane group
     floatx4 h[kCB][NB];
@@ -279,19 +294,25 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
       }
     }
 
-    // ---- per-sample log|det|: the 4 lane groups of a sample, then one store
+    // ---- per-sample log|det| of this layer: the 4 lane groups of a sample
 #pragma unroll
     for (int cb = 0; cb < kCB; ++cb) {
       float v = ld_acc[cb];
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
+      ld_tot[cb] += v;
+    }
+    __syncthreads();                        // the tile now holds this layer's output
+   }   // layers
+#pragma unroll
+    for (int cb = 0; cb < kCB; ++cb) {
+      const float v = ld_tot[cb];
       const int m = (wave * kCB + cb) * 16 + m16;
       if (q == 0 && m < rows && ((wmask >> (m / kFusedFlagRows)) & 1u)) {
         const float o = a.ld_sign * v;
         a.logdet[b0 + m] = a.ld_mode ? a.logdet[b0 + m] + o : o;
       }
     }
-    __syncthreads();
     {
       constexpr int D4 = D / 4;
       float4* dst = reinterpret_cast<float4*>(a.y) + b0 * D4;
@@ -305,7 +326,8 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
 }
 
 template <int DI, int DT, int C, int H, int NBLK, int K, int kCB>
-static int launch_fused(const FusedArgs& a, int inverse, hipStream_t st) {
+static int launch_fused(const FusedStackArgs& sa, int inverse, hipStream_t st) {
+  const FusedArgs& a = sa.a;
   constexpr int kTile = 4 * kCB * 16;
   constexpr int D = DI + DT;
   const size_t lds = ((size_t)kTile * (D + 4) + (size_t)kTile * ((C > 0 ? C : 4) + 4) +
@@ -314,15 +336,15 @@ static int launch_fused(const FusedArgs& a, int inverse, hipStream_t st) {
   const long long resident = 256 * 2;   // workgroups the chip holds at once
   dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
   if (inverse)
-    hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, true, kCB>), grid, dim3(kFBlock), lds, st, a);
+    hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, true, kCB>), grid, dim3(kFBlock), lds, st, sa);
   else
-    hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, false, kCB>), grid, dim3(kFBlock), lds, st, a);
+    hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, false, kCB>), grid, dim3(kFBlock), lds, st, sa);
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }
 
 // Shape family of the exact fp32 kernel: (d_id = d_t, ctx) with H = 128, 8 bins, NBLK residual blocks.
 template <int NBLK>
-static int launch_fused_f32_family(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+static int launch_fused_f32_family(const FusedStackArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
   if (d_id == 32)
     return ctx_dim == 16 ? launch_fused<32, 32, 16, 128, NBLK, 8, 2>(a, inverse, st)
                          : launch_fused<32, 32, 0, 128, NBLK, 8, 2>(a, inverse, st);
@@ -333,11 +355,11 @@ static int launch_fused_f32_family(const FusedArgs& a, int d_id, int ctx_dim, in
 // One- and three-block layers are compiled as their own translation units (-DVCNF_F32_NBLK=1|3, build.py runs
 // them in parallel); the unit without the macro holds the two-block kernels and the C entry points.
 #if defined(VCNF_F32_NBLK) && VCNF_F32_NBLK == 1
-int launch_fused_f32_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+int launch_fused_f32_b1(const FusedStackArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
   return launch_fused_f32_family<1>(a, d_id, ctx_dim, inverse, st);
 }
 #elif defined(VCNF_F32_NBLK) && VCNF_F32_NBLK == 3
-int launch_fused_f32_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+int launch_fused_f32_b3(const FusedStackArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
   return launch_fused_f32_family<3>(a, d_id, ctx_dim, inverse, st);
 }
 #endif
@@ -387,15 +409,84 @@ extern "C" int64_t vcnf_rqs_layer_fused_small_batch_rows(int64_t rows) {
   return prev;
 }
 
-static int launch_f16x3(const FusedArgs& a, int d_id, int ctx_dim, int num_blocks, int inverse, hipStream_t st) {
-  if (a.B <= g_small_batch_rows) {
-    if (num_blocks == 1) return launch_fused_v6s_b1(a, d_id, ctx_dim, inverse, st);
-    if (num_blocks == 2) return launch_fused_v6s_b2(a, d_id, ctx_dim, inverse, st);
-    return launch_fused_v6s_b3(a, d_id, ctx_dim, inverse, st);
+// sa.n_layers == 1: one layer; > 1: a run of layers in one launch (small-batch kernel on the split-half path: the
+// 128-sample kernel has no layer loop)
+static int launch_f16x3(const FusedStackArgs& sa, int d_id, int ctx_dim, int num_blocks, int inverse, hipStream_t st) {
+  if (sa.n_layers > 1 || sa.a.B <= g_small_batch_rows) {
+    if (num_blocks == 1) return launch_fused_v6s_b1(sa, d_id, ctx_dim, inverse, st);
+    if (num_blocks == 2) return launch_fused_v6s_b2(sa, d_id, ctx_dim, inverse, st);
+    return launch_fused_v6s_b3(sa, d_id, ctx_dim, inverse, st);
   }
-  if (num_blocks == 1) return launch_fused_v6_b1(a, d_id, ctx_dim, inverse, st);
-  if (num_blocks == 2) return launch_fused_v6_b2(a, d_id, ctx_dim, inverse, st);
-  return launch_fused_v6_b3(a, d_id, ctx_dim, inverse, st);
+  if (num_blocks == 1) return launch_fused_v6_b1(sa.a, d_id, ctx_dim, inverse, st);
+  if (num_blocks == 2) return launch_fused_v6_b2(sa.a, d_id, ctx_dim, inverse, st);
+  return launch_fused_v6_b3(sa.a, d_id, ctx_dim, inverse, st);
+}
+
+static int run_stack(const float* x, const float* context, float* y, float* logdet, int64_t batch,
+                     const vcnf_rqs_stack_layer* layers, int32_t n_layers, int32_t d_t, int32_t d_id,
+                     int32_t ctx_dim, int32_t hidden, int32_t num_blocks, int32_t precision, int64_t wpack_floats,
+                     const vcnf_rqs_cfg* cfg, int inverse, int ld_mode, float ld_sign, int32_t* bad_disc,
+                     int32_t* sat_count, int32_t* redo_tiles, void* stream) {
+  if (!cfg || !layers) return VCNF_ERR_NULL;
+  if (n_layers < 1 || n_layers > kMaxStackLayers) return VCNF_ERR_SHAPE;
+  if (!vcnf_rqs_layer_fused_supported(d_id, d_t, ctx_dim, hidden, num_blocks, cfg->num_bins, cfg->tails))
+    return VCNF_ERR_UNSUPPORTED;
+  if (precision != VCNF_PREC_F32 && precision != VCNF_PREC_F16X3) return VCNF_ERR_UNSUPPORTED;
+  if (batch < 0) return VCNF_ERR_SHAPE;
+  if (batch == 0) return VCNF_OK;
+  if (!x || !y || !logdet || (ctx_dim > 0 && !context)) return VCNF_ERR_NULL;
+  const bool any_sh = layers[0].shared_w != nullptr;
+  for (int l = 0; l < n_layers; ++l) {
+    const vcnf_rqs_stack_layer& q = layers[l];
+    if (!q.wpack || !q.transform_idx || !q.identity_idx) return VCNF_ERR_NULL;
+    if ((q.shared_w != nullptr) != any_sh || (q.shared_h != nullptr) != any_sh || (q.shared_d != nullptr) != any_sh)
+      return VCNF_ERR_NULL;                 // every layer of a run with the unconditional spline, or none
+  }
+  if (ld_mode != VCNF_LD_STORE && ld_mode != VCNF_LD_ACCUM) return VCNF_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(context)) & 15)
+    return VCNF_ERR_ALIGN;
+  if ((double)cfg->min_bin_width * cfg->num_bins > 1.0 || (double)cfg->min_bin_height * cfg->num_bins > 1.0)
+    return VCNF_ERR_VALUE;
+  if (wpack_floats != vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim, num_blocks)) return VCNF_ERR_SHAPE;
+
+  FusedStackArgs sa;
+  FusedArgs& a = sa.a;
+  a.x = x; a.ctx = context; a.y = y; a.logdet = logdet;
+  a.tf_idx = layers[0].transform_idx; a.id_idx = layers[0].identity_idx;
+  a.sh_w = layers[0].shared_w; a.sh_h = layers[0].shared_h; a.sh_d = layers[0].shared_d;
+  a.wpack = layers[0].wpack; a.wpack_bytes = (unsigned)(wpack_floats * 4);
+  a.bad = bad_disc; a.sat = sat_count; a.redo = redo_tiles; a.B = batch; a.ld_mode = ld_mode; a.ld_sign = ld_sign;
+  const int K = cfg->num_bins;
+  a.c.K = K; a.c.tails = cfg->tails;
+  a.c.lo_x = cfg->left; a.c.hi_x = cfg->right; a.c.span_x = (float)((double)cfg->right - (double)cfg->left);
+  a.c.lo_y = cfg->bottom; a.c.hi_y = cfg->top; a.c.span_y = (float)((double)cfg->top - (double)cfg->bottom);
+  a.c.min_w = cfg->min_bin_width; a.c.min_h = cfg->min_bin_height; a.c.min_d = cfg->min_derivative;
+  a.c.free_w = (float)(1.0 - (double)cfg->min_bin_width * K);
+  a.c.free_h = (float)(1.0 - (double)cfg->min_bin_height * K);
+  a.c.wh_scale = cfg->wh_scale;
+  a.c.edge_logit = (float)log(exp(1.0 - (double)cfg->min_derivative) - 1.0);
+  sa.n_layers = n_layers;
+  for (int l = 0; l < kMaxStackLayers; ++l) {
+    const vcnf_rqs_stack_layer& q = layers[l < n_layers ? l : 0];
+    sa.lay[l] = FusedLayerDesc{q.transform_idx, q.identity_idx, q.shared_w, q.shared_h, q.shared_d, q.wpack};
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (precision == VCNF_PREC_F16X3) return launch_f16x3(sa, d_id, ctx_dim, num_blocks, inverse, st);
+  if (num_blocks == 1) return launch_fused_f32_b1(sa, d_id, ctx_dim, inverse, st);
+  if (num_blocks == 3) return launch_fused_f32_b3(sa, d_id, ctx_dim, inverse, st);
+  return launch_fused_f32_family<2>(sa, d_id, ctx_dim, inverse, st);
+}
+
+extern "C" int32_t vcnf_rqs_stack_fused_max_layers(void) { return kMaxStackLayers; }
+
+extern "C" int vcnf_rqs_stack_fused_f32(const float* x, const float* context, float* y, float* logdet,
+                                        int64_t batch, const vcnf_rqs_stack_layer* layers, int32_t n_layers,
+                                        int32_t d_t, int32_t d_id, int32_t ctx_dim, int32_t hidden,
+                                        int32_t num_blocks, int32_t precision, int64_t wpack_floats,
+                                        const vcnf_rqs_cfg* cfg, int inverse, int ld_mode, float ld_sign,
+                                        int32_t* bad_disc, int32_t* sat_count, int32_t* redo_tiles, void* stream) {
+  return run_stack(x, context, y, logdet, batch, layers, n_layers, d_t, d_id, ctx_dim, hidden, num_blocks, precision,
+                   wpack_floats, cfg, inverse, ld_mode, ld_sign, bad_disc, sat_count, redo_tiles, stream);
 }
 
 extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, float* logdet,
@@ -407,41 +498,12 @@ extern "C" int vcnf_rqs_layer_fused_f32(const float* x, const float* context, fl
                                         const vcnf_rqs_cfg* cfg, int inverse,
                                         int ld_mode, float ld_sign, int32_t* bad_disc, int32_t* sat_count,
                                         int32_t* redo_tiles, void* stream) {
-  if (!cfg || !wpack) return VCNF_ERR_NULL;
-  if (!vcnf_rqs_layer_fused_supported(d_id, d_t, ctx_dim, hidden, num_blocks, cfg->num_bins, cfg->tails))
-    return VCNF_ERR_UNSUPPORTED;
-  if (precision != VCNF_PREC_F32 && precision != VCNF_PREC_F16X3) return VCNF_ERR_UNSUPPORTED;
-  if (batch < 0) return VCNF_ERR_SHAPE;
-  if (batch == 0) return VCNF_OK;
-  if (!x || !y || !logdet || !transform_idx || !identity_idx || (ctx_dim > 0 && !context)) return VCNF_ERR_NULL;
+  if (!wpack) return VCNF_ERR_NULL;
+  if (batch > 0 && (!transform_idx || !identity_idx)) return VCNF_ERR_NULL;
   const bool any_sh = shared_w || shared_h || shared_d;
   if (any_sh && !(shared_w && shared_h && shared_d)) return VCNF_ERR_NULL;
-  if (ld_mode != VCNF_LD_STORE && ld_mode != VCNF_LD_ACCUM) return VCNF_ERR_UNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(context)) & 15)
-    return VCNF_ERR_ALIGN;
-  if ((double)cfg->min_bin_width * cfg->num_bins > 1.0 || (double)cfg->min_bin_height * cfg->num_bins > 1.0)
-    return VCNF_ERR_VALUE;
-
-  FusedArgs a;
-  a.x = x; a.ctx = context; a.y = y; a.logdet = logdet;
-  a.tf_idx = transform_idx; a.id_idx = identity_idx;
-  a.sh_w = shared_w; a.sh_h = shared_h; a.sh_d = shared_d;
-  a.wpack = wpack; a.wpack_bytes = (unsigned)(wpack_floats * 4);
-  a.bad = bad_disc; a.sat = sat_count; a.redo = redo_tiles; a.B = batch; a.ld_mode = ld_mode; a.ld_sign = ld_sign;
-  const int K = cfg->num_bins;
-  a.c.K = K; a.c.tails = cfg->tails;
-  a.c.lo_x = cfg->left; a.c.hi_x = cfg->right; a.c.span_x = (float)((double)cfg->right - (double)cfg->left);
-  a.c.lo_y = cfg->bottom; a.c.hi_y = cfg->top; a.c.span_y = (float)((double)cfg->top - (double)cfg->bottom);
-  a.c.min_w = cfg->min_bin_width; a.c.min_h = cfg->min_bin_height; a.c.min_d = cfg->min_derivative;
-  a.c.free_w = (float)(1.0 - (double)cfg->min_bin_width * K);
-  a.c.free_h = (float)(1.0 - (double)cfg->min_bin_height * K);
-  a.c.wh_scale = cfg->wh_scale;
-  a.c.edge_logit = (float)log(exp(1.0 - (double)cfg->min_derivative) - 1.0);
-  hipStream_t st = (hipStream_t)stream;
-  if (wpack_floats != vcnf_rqs_layer_fused_pack_floats(d_id, d_t, ctx_dim, num_blocks)) return VCNF_ERR_SHAPE;
-  if (precision == VCNF_PREC_F16X3) return launch_f16x3(a, d_id, ctx_dim, num_blocks, inverse, st);
-  if (num_blocks == 1) return launch_fused_f32_b1(a, d_id, ctx_dim, inverse, st);
-  if (num_blocks == 3) return launch_fused_f32_b3(a, d_id, ctx_dim, inverse, st);
-  return launch_fused_f32_family<2>(a, d_id, ctx_dim, inverse, st);
+  const vcnf_rqs_stack_layer one = {transform_idx, identity_idx, wpack, shared_w, shared_h, shared_d};
+  return run_stack(x, context, y, logdet, batch, &one, 1, d_t, d_id, ctx_dim, hidden, num_blocks, precision,
+                   wpack_floats, cfg, inverse, ld_mode, ld_sign, bad_disc, sat_count, redo_tiles, stream);
 }
 #endif  // VCNF_F32_NBLK

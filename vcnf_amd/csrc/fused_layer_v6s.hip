@@ -51,7 +51,8 @@ __device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo) {
 }
 
 template <int DI, int DT, int C, int H, int NBLK, int K, bool INV>
-__global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6s_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6s_kernel(const FusedStackArgs sa) {
+  const FusedArgs& a = sa.a;
   static_assert(H == 128 && K == 8, "4 row blocks of 32 over 4 waves; 3 K - 1 = 23 logits: two features per 48 rows");
   static_assert((DI == 16 || DI == 32) && DT == DI && (C == 0 || C == 16), "shape family");
   constexpr int kBlock = 512;
@@ -76,13 +77,14 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6s_kernel(const Fused
   uint4* act = reinterpret_cast<uint4*>(smem);
   float* xt = smem + 4 * ABUF * 4;                         // [32][XS]  x in, y out (in place)
   uint4* ctxf = reinterpret_cast<uint4*>(xt + kTile * XS); // [hi | lo][lane] context fragment (2 KB)
-  float* tab = reinterpret_cast<float*>(ctxf + (C > 0 ? 2 * 64 : 0));   // [DI][TABW]
-  float* ldt = tab + ((DI * TABW + 3) & ~3);               // [32] identity-half log|det|
+  float* ldt = reinterpret_cast<float*>(ctxf + (C > 0 ? 2 * 64 : 0));   // [32] identity-half log|det|
   float* ldx = ldt + kTile;                                // [8][32] per-wave shares of the transformed half
-  int* tfi = reinterpret_cast<int*>(ldx + 8 * kTile);
-  int* idi = tfi + DT;
-  float* biasf = reinterpret_cast<float*>(idi + DI + 4);   // [NG][lane half][48] last-layer bias (3 KB)
-  int* tflag = reinterpret_cast<int*>(biasf + NG * 96);
+  int* tflag = reinterpret_cast<int*>(ldx + 8 * kTile);
+  // per-layer tables, two sets (the set of the next layer is written while this layer runs):
+  //   tab [DI][TABW] knot tables of the identity half | tfi [DT] | idi [DI + 4] | biasf [NG][lane half][48]
+  constexpr int TABF = (DI * TABW + 3) & ~3;
+  constexpr int TSET = TABF + DT + DI + 4 + NG * 96;
+  float* tsets = reinterpret_cast<float*>(tflag + 4);
 #define VCNF_ACT_HI(BUF) (act + (BUF) * 2 * ABUF)
 #define VCNF_ACT_LO(BUF) (act + (BUF) * 2 * ABUF + ABUF)
 
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6s_kernel(const Fused
   const int c32 = lane & 31;
   const int kg = lane >> 5;
   const RqsConst& c = a.c;
-  const bool shared = a.sh_w != nullptr;
+  const bool shared = sa.lay[0].sh_w != nullptr;     // all layers of a stack or none
   LeanConst lc = make_lean_const(c);
   {
     // wave-uniform: keep them in scalar registers (as vector registers they were spilled around the last layer and
@@ -110,13 +112,12 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6s_kernel(const Fused
   VCNF_TS(0)
 #endif
 
-  const __amdgpu_buffer_rsrc_t wr =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpack), 0, a.wpack_bytes, 0x00020000);
   const int voff = lane * 16;
   const int boff = kg * 64;                 // bias rows of this lane half: [nb][kg][16] floats
   const long long ntiles = (a.B + kTile - 1) / kTile;
 
-  // ---- the first tile's rows and the small tables are requested up front, before any set-up arithmetic
+  const int nlay = sa.n_layers;
+  // ---- the first tile's rows are requested before anything else
   constexpr int D4 = D / 4;
   float4 xpre = make_float4(0.f, 0.f, 0.f, 0.f), cpre = make_float4(0.f, 0.f, 0.f, 0.f);
 #define VCNF_PREFETCH_ROWS(TILE)                                                          \
@@ -137,38 +138,60 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6s_kernel(const Fused
   static_assert(kTile * D4 <= kBlock, "one 16-byte piece of the tile per thread");
   VCNF_PREFETCH_ROWS((long long)blockIdx.x)
   __builtin_amdgcn_sched_barrier(0);
+
+  // ---- per-layer tables (index vectors, last-layer bias, knot tables of the identity half), built by the waves that
+  // sit out the trunk, in two steps so that no barrier waits for memory: ISSUE requests a layer's values into
+  // registers, COMMIT (a few barriers later, when they have long arrived) writes table set SET.  The set of layer
+  // l + 1 is built while layer l runs.
   constexpr int NSET = (NG * 96 + 255) / 256;
-  float bset[NSET];
-  int iset = 0;
-  if (trunk) {
-#pragma unroll
-    for (int k = 0; k < NSET; ++k) bset[k] = tid + 256 * k < NG * 96 ? a.wpack[L::BF + tid + 256 * k] : 0.f;
-    if (tid < DT) iset = a.tf_idx[tid];
-    else if (tid < DT + DI) iset = a.id_idx[tid - DT];
+  static_assert(3 * DI <= 256 && DT + DI <= 256, "one table column / index entry per thread of waves 4-7");
+#define VCNF_SETUP_ISSUE(LAY)                                                             \
+  {                                                                                       \
+    const int u_ = tid - 256;                                                             \
+    _Pragma("unroll") for (int k = 0; k < NSET; ++k)                                      \
+      bset[k] = u_ + 256 * k < NG * 96 ? (LAY).wpack[L::BF + u_ + 256 * k] : 0.f;         \
+    iset = u_ < DT ? (LAY).tf_idx[u_] : (u_ < DT + DI ? (LAY).id_idx[u_ - DT] : 0);       \
+    if (shared && u_ < 3 * DI) {                                                          \
+      const int f_ = u_ % DI;                                                             \
+      SplitLogits p_{(LAY).sh_w + f_ * K, (LAY).sh_h + f_ * K, (LAY).sh_d + f_ * (K - 1), K, 1.f, c.edge_logit, c.tails}; \
+      rqs_table_column_load<K>(p_, u_ / DI, tcol);                                        \
+    }                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
   }
-  __builtin_amdgcn_sched_barrier(0);
-  // (the knot tables' logits are requested before anything waits: one memory latency for the whole set-up)
-  if (shared) {
-    // knot tables of the identity half: one thread per (feature, column: x knots | y knots | derivatives)
-    for (int i = tid; i < 3 * DI; i += kBlock) {
-      const int f = i % DI;
-      SplitLogits p{a.sh_w + f * K, a.sh_h + f * K, a.sh_d + f * (K - 1), K, 1.f, c.edge_logit, c.tails};
-      rqs_build_table_part_k<K>(p, c, tab + f * TABW, 1, i / DI);
-    }
+#define VCNF_SETUP_COMMIT(SET)                                                            \
+  {                                                                                       \
+    float* ts_ = tsets + (SET) * TSET;                                                    \
+    const int u_ = tid - 256;                                                             \
+    _Pragma("unroll") for (int k = 0; k < NSET; ++k)                                      \
+      if (u_ + 256 * k < NG * 96) (ts_ + TABF + DT + DI + 4)[u_ + 256 * k] = bset[k];     \
+    if (u_ < DT + DI) reinterpret_cast<int*>(ts_ + TABF)[u_] = iset;                      \
+    if (shared && u_ < 3 * DI) rqs_table_column_build<K>(tcol, 1.f, c, ts_ + (u_ % DI) * TABW, 1, u_ / DI); \
+  }
+  if (!trunk) {
+    float bset[NSET], tcol[K + 1];
+    int iset;
+    VCNF_SETUP_ISSUE(sa.lay[0])
+    VCNF_SETUP_COMMIT(0)
   }
 
-  if (trunk) {
-#pragma unroll
-    for (int k = 0; k < NSET; ++k)
-      if (tid + 256 * k < NG * 96) biasf[tid + 256 * k] = bset[k];
-    if (tid < DT) tfi[tid] = iset;
-    else if (tid < DT + DI) idi[tid - DT] = iset;
-  }
   bool bad = false;
+  int step = 0;                             // layers done so far: table set of the current layer = step & 1
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long b0 = tile * kTile;
     const int rows = (int)min((long long)kTile, a.B - b0);
     float satm = 0.f;
+    float ldsum = 0.f;                      // threads 0-31: the sample's log|det| over the layers done so far
+   for (int l = 0; l < nlay; ++l, ++step) {
+    const FusedLayerDesc& lay = sa.lay[l];
+    const FusedLayerDesc& nxt = sa.lay[l + 1 < nlay ? l + 1 : 0];
+    const bool first = l == 0;                                    // the tile's rows come from memory
+    const bool more = l + 1 < nlay || tile + gridDim.x < ntiles;   // another layer follows in this workgroup
+    const __amdgpu_buffer_rsrc_t wr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lay.wpack), 0, a.wpack_bytes, 0x00020000);
+    float* tab = tsets + (step & 1) * TSET;
+    int* tfi = reinterpret_cast<int*>(tab + TABF);
+    int* idi = tfi + DT;
+    float* biasf = reinterpret_cast<float*>(idi + DI + 4);
     float ld_acc = 0.f;
     // The phases before the first layer (three barriers), in two pieces: _a stages the tile's rows (its wait for the
     // prefetched rows would also wait for anything requested after them), then each wave kind requests what it needs
@@ -405,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6s_kernel(const Fused
     if (trunk) {
       // ---- first layer (operand in buffer 0), relu(h) -> buffer 1                      resnet.py:92-99
       floatx16 h;
-      prologue_a();
+      if (first) prologue_a();
       {
         half8 w0h[NT0], w0l[NT0];
         floatx16 bias0;
@@ -496,15 +519,19 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6s_kernel(const Fused
       }
     } else {
       // these waves wait through the trunk with a free register file: a deeper ring, filled at once
-      constexpr int RW = 10;
+      constexpr int RW = 8;
       half8 wh[RW], wl[RW];
-      prologue_a();
+      float bset[NSET], tcol[K + 1];
+      int iset;
+      if (first) prologue_a();
       VCNF_RING_FILL(wh, wl, RW, gw)
+      if (more) VCNF_SETUP_ISSUE(nxt)
       prologue_b();
       VCNF_SYNC();
 #pragma unroll
       for (int blk = 0; blk < NBLK; ++blk) {
         VCNF_SYNC();
+        if (blk == 0 && more) VCNF_SETUP_COMMIT((step + 1) & 1)
         VCNF_SYNC();
       }
       if (NG == 8 || wave < NG) last_layer(wh, wl, gw);
@@ -516,16 +543,23 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6s_kernel(const Fused
 #undef VCNF_LOAD_BIAS16
 #undef VCNF_PUBLISH
 
-    if (tile + gridDim.x < ntiles) {
+    if (l + 1 == nlay && tile + gridDim.x < ntiles) {
       VCNF_PREFETCH_ROWS(tile + gridDim.x)
     }
-    // ---- per-sample log|det|: identity half (ldt) + the eight waves' shares, added in a fixed order
+    // ---- per-sample log|det| of this layer: identity half (ldt) + the eight waves' shares, added in a fixed order
     ld_acc += __shfl_xor(ld_acc, 32, 64);
     if (kg == 0) ldx[wave * kTile + c32] = ld_acc;
     if (satm > 65504.f) *tflag = 1;
     VCNF_TS(12)
     VCNF_SYNC();
     VCNF_TS(13)
+    if (tid < kTile) {
+      float v = ldt[tid];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += ldx[w * kTile + tid];
+      ldsum += v;
+    }
+   }   // layers
     // A tile that held a non-finite input or a value beyond the fp16 range is not written at all when the caller
     // gave a flag array: the exact fp32 kernel evaluates it from the untouched inputs (vcnf_rqs_layer_fused_f32,
     // redo_tiles).  Without the array the clamped results are stored and only counted (sat).
@@ -536,10 +570,7 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6s_kernel(const Fused
     }
     if (over && a.redo) continue;
     if (tid < rows) {
-      float v = ldt[tid];
-#pragma unroll
-      for (int w = 0; w < 8; ++w) v += ldx[w * kTile + tid];
-      const float o = a.ld_sign * v;
+      const float o = a.ld_sign * ldsum;
       a.logdet[b0 + tid] = a.ld_mode ? a.logdet[b0 + tid] + o : o;
     }
     {
@@ -563,23 +594,24 @@ __global__ __launch_bounds__(512, 2) void fused_rqs_layer_v6s_kernel(const Fused
 }
 
 template <int DI, int DT, int C, int H, int NBLK, int K>
-static int launch_v6s(const FusedArgs& a, int inverse, hipStream_t st) {
+static int launch_v6s(const FusedStackArgs& sa, int inverse, hipStream_t st) {
+  const FusedArgs& a = sa.a;
   constexpr int D = DI + DT;
   constexpr int TILE = kFusedFlagRows;
-  const size_t lds = (size_t)4 * (H / 16) * 64 * 16 +
-                     ((size_t)TILE * (D + 4) + ((DI * 3 * (K + 1) + 3) & ~3) + TILE + 8 * TILE + D + 8 + (DT / 4) * 96) * 4 +
-                     (C > 0 ? 2 * 64 * 16 : 0) + 64;
+  constexpr size_t TSET = ((DI * 3 * (K + 1) + 3) & ~3) + DT + DI + 4 + (DT / 4) * 96;       // one set of per-layer tables
+  const size_t lds = (size_t)4 * (H / 16) * 64 * 16 + (C > 0 ? 2 * 64 * 16 : 0) +
+                     ((size_t)TILE * (D + 4) + TILE + 8 * TILE + 4 + 2 * TSET) * 4 + 64;
   const long long ntiles = (a.B + TILE - 1) / TILE;
   dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256));
   if (inverse)
-    hipLaunchKernelGGL((fused_rqs_layer_v6s_kernel<DI, DT, C, H, NBLK, K, true>), grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL((fused_rqs_layer_v6s_kernel<DI, DT, C, H, NBLK, K, true>), grid, dim3(512), lds, st, sa);
   else
-    hipLaunchKernelGGL((fused_rqs_layer_v6s_kernel<DI, DT, C, H, NBLK, K, false>), grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL((fused_rqs_layer_v6s_kernel<DI, DT, C, H, NBLK, K, false>), grid, dim3(512), lds, st, sa);
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }
 
 template <int NBLK>
-static int launch_v6s_family(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+static int launch_v6s_family(const FusedStackArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
   if (d_id == 32) {
     return ctx_dim == 16 ? launch_v6s<32, 32, 16, 128, NBLK, 8>(a, inverse, st)
                          : launch_v6s<32, 32, 0, 128, NBLK, 8>(a, inverse, st);
@@ -593,15 +625,15 @@ static int launch_v6s_family(const FusedArgs& a, int d_id, int ctx_dim, int inve
 #define VCNF_V6_NBLK 2
 #endif
 #if VCNF_V6_NBLK == 1
-int launch_fused_v6s_b1(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+int launch_fused_v6s_b1(const FusedStackArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
   return launch_v6s_family<1>(a, d_id, ctx_dim, inverse, st);
 }
 #elif VCNF_V6_NBLK == 2
-int launch_fused_v6s_b2(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+int launch_fused_v6s_b2(const FusedStackArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
   return launch_v6s_family<2>(a, d_id, ctx_dim, inverse, st);
 }
 #else
-int launch_fused_v6s_b3(const FusedArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
+int launch_fused_v6s_b3(const FusedStackArgs& a, int d_id, int ctx_dim, int inverse, hipStream_t st) {
   return launch_v6s_family<3>(a, d_id, ctx_dim, inverse, st);
 }
 #endif

@@ -329,29 +329,31 @@ __device__ __forceinline__ void rqs_build_table_part(const P& p, const RqsConst&
   }
 }
 
-// rqs_build_table_part with the bin count known at compile time: the column's logits are fetched first (independent
-// loads: ONE memory latency - the run-time loops above wait for a load in every iteration, 7 us per workgroup
-// measured in the fused layer kernels, profiles/r03_small_batch.md), then the same operations in the same order:
-// bitwise the same table.
+// rqs_build_table_part with the bin count known at compile time, in two pieces: the column's logits are fetched first
+// (independent loads: ONE memory latency - the run-time loops above wait for a load in every iteration, 7 us per
+// workgroup measured in the fused layer kernels, profiles/r03_small_batch.md), then the same operations in the same
+// order: bitwise the same table.  v: K width / height logits (parts 0 / 1) or the K + 1 derivative logits (part 2).
 template <int K, class P>
-__device__ __forceinline__ void rqs_build_table_part_k(const P& p, const RqsConst& c, float* tab, int stride, int part) {
+__device__ __forceinline__ void rqs_table_column_load(const P& p, int part, float (&v)[K + 1]) {
+#pragma unroll
+  for (int k = 0; k <= K; ++k) v[k] = part == 2 ? p.d(k) : (k < K ? (part == 0 ? p.w(k) : p.h(k)) : 0.f);
+}
+
+template <int K>
+__device__ __forceinline__ void rqs_table_column_build(const float (&v)[K + 1], float scale, const RqsConst& c, float* tab,
+                                                       int stride, int part) {
   float* col = tab + part * (K + 1) * stride;
   if (part == 2) {
-    float d[K + 1];
 #pragma unroll
-    for (int k = 0; k <= K; ++k) d[k] = p.d(k);
-#pragma unroll
-    for (int k = 0; k <= K; ++k) col[k * stride] = c.min_d + softplus_f(d[k]);
+    for (int k = 0; k <= K; ++k) col[k * stride] = c.min_d + softplus_f(v[k]);
     return;
   }
   const bool xs = part == 0;
-  float v[K], e[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) v[k] = xs ? p.w(k) : p.h(k);
+  float e[K];
   float m = -INFINITY;
 #pragma unroll
   for (int k = 0; k < K; ++k) m = fmaxf(m, v[k]);
-  const float sc2 = p.scale * kLog2e;
+  const float sc2 = scale * kLog2e;
   float sum = 0.f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -367,6 +369,13 @@ __device__ __forceinline__ void rqs_build_table_part_k(const P& p, const RqsCons
     cum += fmaf(e[k], g, mn);
     col[(k + 1) * stride] = (k == K - 1) ? (xs ? c.hi_x : c.hi_y) : fmaf(span, cum, lo);
   }
+}
+
+template <int K, class P>
+__device__ __forceinline__ void rqs_build_table_part_k(const P& p, const RqsConst& c, float* tab, int stride, int part) {
+  float v[K + 1];
+  rqs_table_column_load<K>(p, part, v);
+  rqs_table_column_build<K>(v, p.scale, c, tab, stride, part);
 }
 
 template <class P>

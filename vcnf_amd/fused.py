@@ -216,13 +216,31 @@ def precision_of(coupling):
     return PREC_F16X3 if mode == 'fp16x3' else PREC_F32
 
 
-def packed_weights(coupling, prec=None):
+def _param_key(coupling):
+    """(data_ptr, _version) of every conditioner parameter.  ``net.parameters()`` walks the module tree on every call
+    (half of the host time of an eager log_prob at small batches); the walk is done once and remembered as
+    (owner module, name) slots, which are read through ``_parameters`` - a re-assigned Parameter is still seen;
+    refresh_packed() forgets the slots (needed only after sub-MODULES were replaced)."""
+    slots = coupling.__dict__.get('_fused_slots')
+    if slots is None:
+        slots = [(mod, name) for mod in coupling.transform_net.modules() for name in mod._parameters
+                 if mod._parameters[name] is not None]
+        coupling.__dict__['_fused_slots'] = slots
+    key = []
+    for mod, name in slots:
+        p = mod._parameters[name]
+        key.append((p.data_ptr(), p._version))
+    return tuple(key)
+
+
+def packed_weights(coupling, prec=None, key=None):
     """Cached packed buffer of one matrix path; refreshed when any conditioner parameter changed.  A refresh of the
     same size rewrites the existing device buffer in place, so a captured HIP graph that holds its address
     (vcnf_amd.graphs) sees the new weights."""
     net = coupling.transform_net
     prec = precision_of(coupling) if prec is None else prec
-    key = tuple((p.data_ptr(), p._version) for p in net.parameters())
+    if key is None:
+        key = _param_key(coupling)
     packs = coupling.__dict__.setdefault('_fused_pack', {})
     cache = packs.get(prec)
     if cache is None or cache[0] != key:
@@ -249,11 +267,87 @@ def run(coupling, inputs, context, sampling, log_q=None, sign=1.0):
     shared = coupling.unconditional_transform.logits() if coupling.unconditional_transform is not None else None
     prec = precision_of(coupling)
     safe = prec == PREC_F16X3 and getattr(coupling, 'range_safe', True)
+    key = _param_key(coupling)
     return _lib.rqs_layer_fused(inputs, context, coupling._index32('tf'), coupling._index32('id'),
                                 net.context_features or 0, net.hidden_features, len(net.blocks),
-                                prec, packed_weights(coupling, prec), shared, coupling._cfg(True), sampling,
+                                prec, packed_weights(coupling, prec, key), shared, coupling._cfg(True), sampling,
                                 logdet=log_q, sign=sign,
-                                wpack_f32=packed_weights(coupling, PREC_F32) if safe else None)
+                                wpack_f32=packed_weights(coupling, PREC_F32, key) if safe else None)
+
+
+# ---------------------------------------------------------------- runs of layers in one launch (small batches)
+def _stack_sig(coupling, context):
+    """What must agree between the layers of one launch: shape, conditioner structure, spline configuration, matrix
+    path, range policy; None for a layer the fused kernels do not cover."""
+    if not (coupling.fused and eligible(coupling, context)):
+        return None
+    net = coupling.transform_net
+    cfg = coupling._cfg(True)
+    return (coupling.num_identity_features, coupling.num_transform_features, net.context_features or 0,
+            net.hidden_features, len(net.blocks), precision_of(coupling), bool(getattr(coupling, 'range_safe', True)),
+            coupling.unconditional_transform is not None,
+            tuple(getattr(cfg, f) for f, _ in cfg._fields_))
+
+
+def plan_stack(order, start, z, context):
+    """Longest run order[start:end] (at least two, at most the kernel's limit) of CoupledRationalQuadraticSpline layers
+    that one launch of vcnf_rqs_stack_fused_f32 evaluates, or None: 2-D fp32 inputs on the device, no gradient
+    required, a batch small enough for the 32-sample-tile kernel, every layer fused-eligible with ONE shape, spline
+    configuration and matrix path.  Returns (end, couplings, signature)."""
+    from .flows.neural_spline.wrapper import CoupledRationalQuadraticSpline
+    if z.dim() != 2 or z.dtype != torch.float32 or not z.is_cuda or z.shape[0] > _lib.small_batch_rows():
+        return None
+    lim = int(_lib.lib().vcnf_rqs_stack_fused_max_layers())
+    run, sig = [], None
+    for flow in order[start:start + lim]:
+        if type(flow) is not CoupledRationalQuadraticSpline:
+            break
+        cp = flow.prqct
+        if cp.per_feature or cp._needs_grad(z, context):
+            break
+        s = _stack_sig(cp, context)
+        if s is None or (sig is not None and s != sig):
+            break
+        sig = s
+        run.append(cp)
+    if len(run) < 2:
+        return None
+    return start + len(run), run, sig
+
+
+def run_stack(run, sig, z, context, sampling, log_q, sign):
+    """Execute a planned run in one launch (plus the fp32 re-evaluation launch of the range-safe split-half path, which
+    returns at once unless a tile was flagged).  The ctypes layer table is cached on the first coupling of the run and
+    refilled with the current addresses on every call (packed buffers are rewritten in place, so they rarely change)."""
+    d_id, d_t, ctx_dim, hidden, blocks, prec, safe = sig[:7]
+    first = run[0]
+    cache = first.__dict__.setdefault('_fused_rqs_stack', {})
+    ids = (tuple(id(c) for c in run), bool(sampling))
+    if cache.get('ids') != ids:
+        cache.clear()
+        cache['ids'] = ids
+        cache['tab'] = (_lib.RqsStackLayer * len(run))()
+        cache['tab32'] = (_lib.RqsStackLayer * len(run))()
+    want32 = prec == PREC_F16X3 and safe
+    tab, tab32 = cache['tab'], cache['tab32']
+    keep = []                                   # the tensors behind the table's addresses, alive through the launch
+    for i, cp in enumerate(run):
+        key = _param_key(cp)
+        wp = packed_weights(cp, prec, key)
+        tf, idx = cp._index32('tf'), cp._index32('id')
+        shared = cp.unconditional_transform.logits() if cp.unconditional_transform is not None else (None, None, None)
+        keep.append((wp, tf, idx, shared))
+        for t, w in ((tab, wp),) + (((tab32, packed_weights(cp, PREC_F32, key)),) if want32 else ()):
+            e = t[i]
+            e.transform_idx, e.identity_idx, e.wpack = tf.data_ptr(), idx.data_ptr(), w.data_ptr()
+            e.shared_w = shared[0].data_ptr() if shared[0] is not None else None
+            e.shared_h = shared[1].data_ptr() if shared[1] is not None else None
+            e.shared_d = shared[2].data_ptr() if shared[2] is not None else None
+            keep.append(w)
+    out = _lib.rqs_stack_fused(z, context, tab, tab32 if want32 else None, keep[0][0].numel(), d_t, d_id, ctx_dim, hidden,
+                               blocks, prec, first._cfg(True), sampling, logdet=log_q, sign=sign)
+    del keep
+    return out
 
 
 def refresh_packed(module):
@@ -265,6 +359,8 @@ def refresh_packed(module):
     Buffers are rewritten in place at the next use, so a captured HIP graph keeps its addresses."""
     for m in module.modules():
         d = m.__dict__
+        d.pop('_fused_slots', None)
+        d.pop('_fused_rqs_stack', None)
         if isinstance(d.get('_fused_pack'), dict):
             for prec, (key, buf) in list(d['_fused_pack'].items()):
                 d['_fused_pack'][prec] = (None, buf)
