@@ -383,6 +383,50 @@ def bench_train(args, device, rank, world, steps=None, warmup=None):
     return out
 
 
+def bench_small_batch(device, batch=2048, reps=30):
+    """log_prob latency of the C3 model at the batch size of the reference's own drivers (/root/reference/run.py:45-47:
+    1024 - 2048 samples): eager (an unchanged caller of NormalizingFlow.log_prob) and replayed from a HIP graph
+    (nf.GraphedFlow).  At this size the 12 layers are ONE launch of the 32-sample-tile kernel
+    (vcnf_rqs_stack_fused_f32, csrc/fused_layer_v6s.hip) + the fp32 re-evaluation launch + the Gaussian end cap."""
+    torch.manual_seed(0)
+    flows = [nf.flows.CoupledRationalQuadraticSpline(D, BLOCKS, HIDDEN, BINS, tail_bound=TAIL, reverse_mask=bool(i % 2),
+                                                    num_context_channels=CTX) for i in range(LAYERS)]
+    model = nf.NormalizingFlow(nf.distributions.DiagGaussian(D), flows).to(device).eval()
+    gen = torch.Generator(device=device).manual_seed(2000)
+    x = torch.randn(batch, D, device=device, generator=gen)
+    ctx = torch.randn(batch, CTX, device=device, generator=gen)
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    with torch.no_grad():
+        eager = timed(lambda: model.log_prob(x, ctx))
+        per_layer = None
+        model.fuse_rqs_stacks = False
+        per_layer = timed(lambda: model.log_prob(x, ctx))
+        model.fuse_rqs_stacks = True
+    g = nf.GraphedFlow(model, batch, CTX)
+    graph = timed(lambda: g.log_prob(x, ctx))
+    redone = nf.range_redo_count(device)
+    nf.check_discriminant(device)
+    out = {"metric": "log_prob latency, config C3 at the reference drivers' batch size", "unit": "ms",
+           "higher_is_better": False, "batch": batch, "eager_ms": round(eager * 1e3, 4), "graph_ms": round(graph * 1e3, 4),
+           "eager_one_launch_per_layer_ms": round(per_layer * 1e3, 4),
+           "transforms_per_s_graph": round(batch / graph, 1), "dtype": "f32 results on fp16x3 split operands (see dtype)",
+           "range_redo_tiles": int(redone),
+           "config": {"workload": "C3 model, log_prob of %d samples, one launch for the 12 coupling layers" % batch,
+                      "layers": LAYERS}}
+    del model, g, x, ctx
+    torch.cuda.empty_cache()
+    return out
+
+
 def extra_configs(args, device):
     """Short legs of BASELINE.json's other GPU configurations and of the training step, for the default JSON line
     (N = 1): 1 warm-up + 2 timed steps each, so that every configuration's figure is driver-visible."""
@@ -395,6 +439,7 @@ def extra_configs(args, device):
             out[cfg]["whole_step_frac_of_yardstick"] = r["whole_step_frac_of_yardstick"]
     r = bench_train(args, device, 0, 1, steps=2, warmup=1)
     out["C3-train"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline")}
+    out["C3-latency-2048"] = bench_small_batch(device)
     return out
 
 

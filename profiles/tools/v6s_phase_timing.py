@@ -19,13 +19,23 @@ NAMES = ["kernel entry", "set-up done (index / bias / knot tables)", "first barr
          "block 0 second layer + gate + publish", "trunk done (all barriers)", "last-layer matrix steps done",
          "splines done, log-det share written", "barrier", "outputs issued", "outputs landed"]
 torch.manual_seed(0)
-lay = nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8, num_context_channels=16).cuda().eval()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+NL = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # > 1: a run of layers in one launch; the stamps after the
+                                                            # identity half are those of the LAST layer
+from vcnf_amd import fused as fz
+flows = [nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8, reverse_mask=bool(i % 2), num_context_channels=16) for i in range(NL)]
+model = nf.NormalizingFlow(nf.distributions.DiagGaussian(64), flows).cuda().eval()
+lay = flows[0]
 with torch.no_grad():
     xb, cb = torch.randn(B, 64, device='cuda'), torch.randn(B, 16, device='cuda')
     for dirn in ("inverse", "forward"):
         for _ in range(3):
-            y, _ = getattr(lay, dirn)(xb, context=cb)
+            if NL == 1:
+                y, _ = getattr(lay, dirn)(xb, context=cb)
+            else:
+                order = list(reversed(model.flows)) if dirn == "inverse" else list(model.flows)
+                end, run, sig = fz.plan_stack(order, 0, xb, cb)
+                y, _ = fz.run_stack(run, sig, xb, cb, dirn == "forward", None, 1.0)
         torch.cuda.synchronize()
         for w, row in ((0, 0), (4, 0)):
             v = y[0, 32 * (w // 4):32 * (w // 4) + 32].double().cpu()

@@ -322,6 +322,49 @@ def test_reverse_kld_and_alpha_div(hip):
     assert len(out) == 4 and len(out[1]) == len(model.flows) and out[3].shape == (64,)
 
 
+def test_graphed_train_step_matches_eager_steps(hip):
+    """nf.GraphedTrainStep: zero_grad + forward_kld + backward + optimiser step captured into ONE HIP graph.  Replayed
+    on fresh batches it follows the eager loop on a copy of the model: same losses, same parameters afterwards (plain
+    SGD: the update is linear in the gradient, so rounding-level differences stay at rounding level; with Adam the
+    update lr * m / sqrt(v) turns a rounding-level gradient into a full +-lr step and two EAGER runs already differ by
+    several lr), and the evaluation path sees the updated weights.  An Adam step is captured as well and must train."""
+    import copy
+    torch.manual_seed(9)
+    model = _c3_small(3).to("cuda")
+    twin = copy.deepcopy(model)
+    B = 1024
+    data = [(torch.randn(B, 64, device="cuda") * 0.7 + 0.3, torch.randn(B, 16, device="cuda")) for _ in range(6)]
+    opt = torch.optim.SGD(model.parameters(), lr=2e-3)
+    opt2 = torch.optim.SGD(twin.parameters(), lr=2e-3)
+    step = nf.GraphedTrainStep(model, opt, batch=B, context_features=16, warmup=2)
+    # the capture's warm-up performs 2 real steps on the first batch: the eager twin does the same
+    losses, want = [], []
+    for i, (x, c) in enumerate(data):
+        for _ in range(3 if i == 0 else 1):
+            opt2.zero_grad(set_to_none=True)
+            l2 = twin.forward_kld(x, context=c)
+            l2.backward()
+            opt2.step()
+        want.append(float(l2.detach()))
+        losses.append(float(step(x, c).detach()))
+    assert np.isfinite(losses).all()
+    assert np.allclose(losses, want, rtol=1e-5, atol=1e-4), [a - b for a, b in zip(losses, want)]
+    for (n, p), (_, q) in zip(model.named_parameters(), twin.named_parameters()):
+        d = (p - q).abs()
+        assert float(d.max()) <= 1e-5 + 1e-4 * float(q.abs().max()), (n, float(d.max()))
+    with torch.no_grad():
+        x, c = data[-1]
+        assert torch.allclose(model.log_prob(x, c), twin.log_prob(x, c), rtol=1e-4, atol=2e-3)
+    # Adam: state on the device (capturable=True) - a host-side step counter is refused
+    with pytest.raises(ValueError):
+        nf.GraphedTrainStep(model, torch.optim.Adam(model.parameters(), lr=1e-3), batch=B, context_features=16)
+    adam = nf.GraphedTrainStep(model, torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True), batch=B, context_features=16)
+    x, c = data[0]
+    la = [float(adam(x, c).detach()) for _ in range(8)]
+    assert np.isfinite(la).all() and la[-1] < la[0] - 0.3, la
+    nf.check_discriminant()
+
+
 def test_nsf_stack_with_lu_linear_permute_trains(hip):
     """The neural-spline-flow layout of arXiv 1906.04032 (spline coupling + LULinearPermute per
     layer): gradients against the oracle stack in fp64, then a few optimiser steps."""

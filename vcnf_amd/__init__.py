@@ -15,7 +15,7 @@ from ._lib import lib, lib_path, VcnfError, check_discriminant, check_saturation
 from . import utils, nets, flows, distributions                  # noqa: F401
 from .core import NormalizingFlow, MultiscaleFlow                # noqa: F401
 from .sharded import ShardedEvaluator, shard_bounds              # noqa: F401
-from .graphs import GraphedFlow                                  # noqa: F401
+from .graphs import GraphedFlow, GraphedTrainStep                # noqa: F401
 from .fused import refresh_packed                                # noqa: F401
 
 __version__ = "0.1.0"

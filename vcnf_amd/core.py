@@ -79,7 +79,7 @@ class NormalizingFlow(_PackedWeightsMixin, nn.Module):
                     continue
             # a run of one-kernel RQS coupling layers at a small batch is ONE launch (the tile stays in LDS)
             if self.fuse_rqs_stacks and type(flow) is CoupledRationalQuadraticSpline:
-                plan = fused.plan_stack(order, i, z, context)
+                plan = fused.cached_plan_stack(self, order, i, z, context)
                 if plan is not None:
                     resume, run, sig = plan
                     z = fused.run_stack(run, sig, z, context, False, log_q, 1.0)[0]
@@ -132,7 +132,7 @@ class NormalizingFlow(_PackedWeightsMixin, nn.Module):
                                                log_q, -1.0)[0]
                     continue
             if self.fuse_rqs_stacks and type(flow) is CoupledRationalQuadraticSpline:
-                plan = fused.plan_stack(order, i, z, context)
+                plan = fused.cached_plan_stack(self, order, i, z, context)
                 if plan is not None:
                     resume, run, sig = plan
                     z = fused.run_stack(run, sig, z, context, True, log_q, -1.0)[0]

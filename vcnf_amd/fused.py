@@ -315,6 +315,42 @@ def plan_stack(order, start, z, context):
     return start + len(run), run, sig
 
 
+def _stack_stamp(cp):
+    return (cp.fused, cp.fused_precision, getattr(cp, 'range_safe', True), cp.tails, cp.num_bins, cp.per_feature,
+            cp.unconditional_transform is None, id(cp.transform_net), cp.tail_bound if not torch.is_tensor(cp.tail_bound) else id(cp.tail_bound))
+
+
+def cached_plan_stack(owner, order, start, z, context):
+    """plan_stack memoised on the calling model for evaluations without autograd (the plan costs a library call and a
+    spline configuration per layer - more than the launch it saves at these batch sizes).  A cached plan is reused
+    while the run's modules and their routing switches are what they were; shape, dtype, device, the batch-size
+    threshold and the context width are part of the key."""
+    if torch.is_grad_enabled():
+        return plan_stack(order, start, z, context)
+    if z.dim() != 2 or z.dtype != torch.float32 or not z.is_cuda:
+        return None
+    small = z.shape[0] <= _lib.small_batch_rows()
+    key = (start, len(order), id(order[start]), z.shape[1], small, None if context is None else tuple(context.shape[1:]),
+           DEFAULT_PRECISION)
+    plans = owner.__dict__.setdefault('_rqs_stack_plans', {})
+    hit = plans.get(key)
+    if hit is not None:
+        plan, mods, stamp = hit
+        if all(a is b for a, b in zip(order[start:start + len(mods)], mods)) and \
+                stamp == tuple(_stack_stamp(f.prqct) for f in mods if hasattr(f, 'prqct')):
+            return plan
+    plan = plan_stack(order, start, z, context)
+    from .flows.neural_spline.wrapper import CoupledRationalQuadraticSpline
+    lim = int(_lib.lib().vcnf_rqs_stack_fused_max_layers())
+    # what the plan looked at: the run and the flow that ended it
+    n = (plan[0] - start if plan is not None else 0) + 1
+    mods = [f for f in order[start:start + min(n, lim)] if type(f) is CoupledRationalQuadraticSpline]
+    if len(plans) > 64:
+        plans.clear()
+    plans[key] = (plan, mods, tuple(_stack_stamp(f.prqct) for f in mods))
+    return plan
+
+
 def run_stack(run, sig, z, context, sampling, log_q, sign):
     """Execute a planned run in one launch (plus the fp32 re-evaluation launch of the range-safe split-half path, which
     returns at once unless a tile was flagged).  The ctypes layer table is cached on the first coupling of the run and
@@ -361,6 +397,7 @@ def refresh_packed(module):
         d = m.__dict__
         d.pop('_fused_slots', None)
         d.pop('_fused_rqs_stack', None)
+        d.pop('_rqs_stack_plans', None)
         if isinstance(d.get('_fused_pack'), dict):
             for prec, (key, buf) in list(d['_fused_pack'].items()):
                 d['_fused_pack'][prec] = (None, buf)
