@@ -326,7 +326,9 @@ __global__ __launch_bounds__(kFABlock) void fused_affine_layer_kernel(const Fuse
   const long long nwt = (a.B + 15) / 16;                       // wave tiles
   const long long wstride = (long long)gridDim.x * (kFABlock / 64);
   const int n16 = 16 * D;
-  for (long long wt = (long long)blockIdx.x * (kFABlock / 64) + wave; wt < nwt; wt += wstride) {
+  // wave-tile t = blockIdx + gridDim * (wave + 4 k): with fewer tiles than waves on the chip every workgroup runs ONE
+  // wave (2048 samples = 128 tiles on 128 compute units instead of 32; waves are independent, see above)
+  for (long long wt = blockIdx.x + (long long)gridDim.x * wave; wt < nwt; wt += wstride) {
     const long long b0 = wt * 16;
     const int rows = (int)min(16LL, a.B - b0);
     const int nvalid = rows * D;
@@ -429,7 +431,9 @@ __global__ __launch_bounds__(kFABlock) void fused_affine_stack_kernel(const Fuse
   float* s1 = s0 + nrw;
   const long long nwt = (a.B + RW - 1) / RW;
   const long long wstride = (long long)gridDim.x * (kFABlock / 64);
-  for (long long wt = (long long)blockIdx.x * (kFABlock / 64) + wave; wt < nwt; wt += wstride) {
+  // wave-tile t = blockIdx + gridDim * (wave + 4 k): with fewer tiles than waves on the chip every workgroup runs ONE
+  // wave (2048 samples = 128 tiles on 128 compute units instead of 32; waves are independent, see above)
+  for (long long wt = blockIdx.x + (long long)gridDim.x * wave; wt < nwt; wt += wstride) {
     const long long b0 = wt * RW;
     const int rows = (int)min((long long)RW, a.B - b0);
     const int nvalid = rows * D;
@@ -504,7 +508,7 @@ static int launch_fa_stack(const FusedAffineStackArgs& sa, hipStream_t st) {
   const int rw = sa.wpack_h3 ? 16 * VCNF_FA_NCB : 16;     // rows of a wave's strip
   const size_t lds = (size_t)4 * 2 * rw * sa.base.D * sizeof(float);
   if (lds > 64 * 1024) return VCNF_ERR_SHAPE;
-  const long long ntiles = (sa.base.B + 4 * rw - 1) / (4 * rw);
+  const long long ntiles = (sa.base.B + rw - 1) / rw;          // one workgroup per wave-tile until the chip is full
   const long long cap = 256 * 8;
   dim3 grid((unsigned)(ntiles < cap ? ntiles : cap));
   if (sa.wpack_h3)
@@ -518,7 +522,7 @@ template <int KIG, int HB, int OBM>
 static int launch_fa(const FusedAffineArgs& a, hipStream_t st) {
   const size_t lds = (size_t)4 * 16 * a.D * sizeof(float);
   if (lds > 64 * 1024) return VCNF_ERR_SHAPE;
-  const long long ntiles = (a.B + 63) / 64;
+  const long long ntiles = (a.B + 15) / 16;                    // one workgroup per wave-tile until the chip is full
   const long long cap = 256 * 8;
   dim3 grid((unsigned)(ntiles < cap ? ntiles : cap));
   hipLaunchKernelGGL((fused_affine_layer_kernel<KIG, HB, OBM>), grid, dim3(kFABlock), lds, st, a);

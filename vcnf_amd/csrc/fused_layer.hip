@@ -61,7 +61,7 @@ __device__ __forceinline__ void bias_block(__amdgpu_buffer_rsrc_t rsrc, int qoff
   for (int cb = 0; cb < kCB; ++cb) acc[cb] = v;
 }
 
-template <int DI, int DT, int C, int H, int NBLK, int K, bool INV, int kCB>
+template <int DI, int DT, int C, int H, int NBLK, int K, bool INV, int kCB, bool STACK>
 __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const FusedStackArgs sa) {
   // sa.n_layers coupling layers of one shape applied in order to each tile (1: the single-layer entry point); the
   // tile stays in LDS between layers, log|det| is summed over the layers in registers (core.py:144-183)
@@ -95,7 +95,9 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
   const int q = lane >> 4;
   const RqsConst& c = a.c;
   const bool shared = sa.lay[0].sh_w != nullptr;    // all layers of a stack or none
-  const int nlay = sa.n_layers;
+  // STACK = false: the single-layer instantiation (layer count known at compile time: the layer loop and its
+  // bookkeeping fold away - with them in registers the kernel spilled and lost 8 % at 1M samples)
+  const int nlay = STACK ? sa.n_layers : 1;
 
   if (a.redo) {
     // re-evaluation pass behind the split-half kernel: normally no tile is flagged - leave before any set-up
@@ -108,8 +110,23 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
   }
 
   const long long ntiles = (a.B + kTile - 1) / kTile;
+  // index vectors and knot tables of one layer -> LDS
+  auto setup_layer = [&](const FusedLayerDesc& d) {
+    for (int i = tid; i < DT; i += kFBlock) tfi[i] = d.tf_idx[i];
+    for (int i = tid; i < DI; i += kFBlock) idi[i] = d.id_idx[i];
+    if (shared) {
+      // knot tables of the identity half: one thread per (feature, column: x knots | y knots | derivatives)
+      for (int i = tid; i < 3 * DI; i += kFBlock) {
+        const int f = i % DI;
+        SplitLogits p{d.sh_w + f * K, d.sh_h + f * K, d.sh_d + f * (K - 1), K, 1.f, c.edge_logit, c.tails};
+        rqs_build_table_part_k<K>(p, c, tab + f * TABW, 1, i / DI);
+      }
+    }
+  };
+  if (!STACK) setup_layer(sa.lay[0]);       // single layer: once per launch, outside the tile loop (the first
+                                            // __syncthreads() of the loop publishes it)
   bool bad = false;
-  int have = -1;                            // layer whose index vectors / knot tables are in LDS
+  int have = -1;                            // STACK: layer whose index vectors / knot tables are in LDS
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // re-evaluation pass behind the split-half kernel: only the tiles it flagged (and did not write)
     // (one flag per 32 rows: a flagged quarter is written, the others are left as the split-half kernel wrote them)
@@ -149,19 +166,10 @@ __global__ __launch_bounds__(kFBlock, 2) void fused_rqs_layer_kernel(const Fused
     for (int cb = 0; cb < kCB; ++cb) ld_tot[cb] = 0.f;
    for (int l = 0; l < nlay; ++l) {
     const FusedLayerDesc& lay = sa.lay[l];
-    if (have != l) {
-      // this layer's index vectors and knot tables (once per launch for a single layer)
+    if (STACK && have != l) {
+      // this layer's index vectors and knot tables
       if (have >= 0) __syncthreads();
-      for (int i = tid; i < DT; i += kFBlock) tfi[i] = lay.tf_idx[i];
-      for (int i = tid; i < DI; i += kFBlock) idi[i] = lay.id_idx[i];
-      if (shared) {
-        // knot tables of the identity half: one thread per (feature, column: x knots | y knots | derivatives)
-        for (int i = tid; i < 3 * DI; i += kFBlock) {
-          const int f = i % DI;
-          SplitLogits p{lay.sh_w + f * K, lay.sh_h + f * K, lay.sh_d + f * (K - 1), K, 1.f, c.edge_logit, c.tails};
-          rqs_build_table_part_k<K>(p, c, tab + f * TABW, 1, i / DI);
-        }
-      }
+      setup_layer(lay);
       __syncthreads();
       have = l;
     }
@@ -335,10 +343,15 @@ static int launch_fused(const FusedStackArgs& sa, int inverse, hipStream_t st) {
   const long long ntiles = (a.B + kTile - 1) / kTile;
   const long long resident = 256 * 2;   // workgroups the chip holds at once
   dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
-  if (inverse)
-    hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, true, kCB>), grid, dim3(kFBlock), lds, st, sa);
+  if (sa.n_layers > 1) {
+    if (inverse)
+      hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, true, kCB, true>), grid, dim3(kFBlock), lds, st, sa);
+    else
+      hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, false, kCB, true>), grid, dim3(kFBlock), lds, st, sa);
+  } else if (inverse)
+    hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, true, kCB, false>), grid, dim3(kFBlock), lds, st, sa);
   else
-    hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, false, kCB>), grid, dim3(kFBlock), lds, st, sa);
+    hipLaunchKernelGGL((fused_rqs_layer_kernel<DI, DT, C, H, NBLK, K, false, kCB, false>), grid, dim3(kFBlock), lds, st, sa);
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }
 
