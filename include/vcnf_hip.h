@@ -370,6 +370,18 @@ int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, flo
                              int ld_mode, float ld_sign, int32_t* bad_disc, int32_t* sat_count,
                              int32_t* redo_tiles, void* stream);
 
+/* Dense layer at training batch sizes on the fp16 split-half matrix path (csrc/linear_f16x3.hip):
+ *   y[b, n] = sum_k x[b, k] * A[n, k] (+ bias[n]),  A[n, k] = w[n * ldn + k * ldk],  x [batch, k], y [batch, n]
+ * = nn.Linear's forward (w = weight [n, k]: ldn = k, ldk = 1; nets/resnet.py:42-57, 92-106) and its input gradient
+ * g_x = g_y W (w = weight [k, n]: ldn = 1, ldk = n), i.e. what autograd computes for the conditioner's dense layers
+ * in NormalizingFlow.forward_kld (core.py:30-65).  The weights are read in their natural fp32 layout and split in
+ * registers; arithmetic as VCNF_PREC_F16X3 of vcnf_rqs_layer_fused_f32 (lo*lo kept for k <= 48).  k % 16 == 0,
+ * n % 4 == 0, and n <= 128 when k > 128.  x, y 16-byte aligned.  Values beyond +-65504 (or NaN inputs) are clamped
+ * and counted in sat_count (device int32, may be NULL) once per 64-sample tile. */
+int vcnf_linear_f16x3_supported(int32_t k, int32_t n);
+int vcnf_linear_f16x3_f32(const float* x, const float* w, const float* bias, float* y, int64_t batch,
+                          int32_t k, int32_t n, int64_t ldn, int64_t ldk, int32_t* sat_count, void* stream);
+
 /* A run of n_layers (<= vcnf_rqs_stack_fused_max_layers() = 16) RQS coupling layers of ONE shape and one spline
  * configuration in a single launch: the body of NormalizingFlow.log_prob / sample over consecutive
  * CoupledRationalQuadraticSpline layers (core.py:144-183 around coupling.py:70-125).  `layers` is a HOST array in

@@ -1,0 +1,27 @@
+"""C3 Adam step on forward_kld at the reference drivers batch sizes: eager loop against nf.GraphedTrainStep (one HIP graph per step)."""
+import sys, time
+import os
+sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))]
+import torch
+import vcnf_amd as nf
+torch.manual_seed(0)
+def mk():
+    flows = [nf.flows.CoupledRationalQuadraticSpline(64, 2, 128, 8, reverse_mask=bool(i % 2), num_context_channels=16) for i in range(12)]
+    return nf.NormalizingFlow(nf.distributions.DiagGaussian(64), flows).cuda()
+for B in (1024, 2048, 16384):
+    x, c = torch.randn(B, 64, device='cuda'), torch.randn(B, 16, device='cuda')
+    model = mk()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
+    def eager():
+        opt.zero_grad(set_to_none=True)
+        loss = model.forward_kld(x, context=c); loss.backward(); opt.step()
+    for _ in range(3): eager()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(10): eager()
+    torch.cuda.synchronize(); te = (time.perf_counter() - t) / 10
+    step = nf.GraphedTrainStep(model, opt, batch=B, context_features=16)
+    for _ in range(3): step(x, c)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(20): step(x, c)
+    torch.cuda.synchronize(); tg = (time.perf_counter() - t) / 20
+    print("C3 Adam step B=%d: eager %.2f ms (%.2f M samples/s), one HIP graph %.2f ms (%.2f M samples/s)" % (B, te * 1e3, B / te / 1e6, tg * 1e3, B / tg / 1e6), flush=True)

@@ -36,6 +36,7 @@ import numpy as np
 import pytest
 import torch
 
+import vcnf_amd as nf
 from vcnf_amd import _lib
 
 pytestmark = pytest.mark.gpu
@@ -169,3 +170,43 @@ def test_probe_matches_fused_kernel_arithmetic(hip):
     diff = np.abs(y.numpy() - acc)
     print("\nprobe fp32 mode vs emulated fma chain: max abs diff %.3g, exact in %.2f %% of entries" % (diff.max(), 100.0 * (diff == 0).mean()))
     assert diff.max() <= 4 * np.spacing(np.abs(acc).max())
+
+
+@pytest.mark.parametrize("k,n", [(48, 128), (128, 128), (16, 128), (128, 736), (128, 48), (736, 128), (128, 20), (64, 128), (128, 96), (64, 96)])
+def test_training_linear_f16x3_error_not_above_library_fp32(hip, k, n):
+    """csrc/linear_f16x3.hip - nn.Linear's forward and input gradient on the training path at large batches (weights in
+    their natural layout, split in registers) - against an fp64 product: mean and p99.9 error not above those of the
+    library's fp32 GEMM on the same operands (the split-half path rounds the accumulator k / 16 times instead of k
+    times); ragged batches (1 row, a partial tile), output widths that are not whole 32-row blocks (48, 20), a reduction
+    longer than one staged chunk (736), and no clamping on these inputs."""
+    gen = torch.Generator().manual_seed(100 + k + n)
+    for Bt in (1, 63, 64 * 40 + 17):
+        x = torch.randn(Bt, k, generator=gen).cuda()
+        w = (torch.randn(n, k, generator=gen) / k ** 0.5).cuda()
+        b = torch.randn(n, generator=gen).cuda()
+        g = torch.randn(Bt, n, generator=gen).cuda()
+        nf.check_saturation()
+        cases = [("forward", _lib.linear_f16x3(x, w, b), x.double() @ w.double().t() + b.double(), torch.addmm(b, x, w.t()),
+                  (x.abs().double() @ w.abs().double().t() + b.abs().double()))]
+        if _lib.lib().vcnf_linear_f16x3_supported(n, k):          # the input gradient reduces over n
+            cases.append(("dgrad", _lib.linear_f16x3(g, w, None, input_grad=True), g.double() @ w.double(), g @ w,
+                          g.abs().double() @ w.abs().double()))
+        for what, got, ref, lib, scale in cases:
+            e_sp, e_lib = (got.double() - ref).abs(), (lib.double() - ref).abs()
+            # every entry within a few fp32 roundings of the dot product's scale sum |x w| (any batch size) ...
+            assert bool((e_sp <= 4 * 2.0 ** -24 * scale + 1e-30).all()), (Bt, what, float((e_sp / scale).max()))
+            if Bt > 1000:                                          # ... and, with enough entries for a statistic, not above the library
+                # (16-deep reductions: the fp32 chain rounds only 16 times - the split-half path is level with it, not
+                # below: 0.8-1.1x, the gate-layer finding of test_split_half_gemm_error_not_above_fp32_mfma)
+                depth = k if what == "forward" else n
+                assert float(e_sp.mean()) <= (1.15 if depth <= 16 else 1.05) * float(e_lib.mean()), \
+                    (what, float(e_sp.mean()), float(e_lib.mean()))
+                q = lambda e: float(e.flatten()[::3].quantile(0.999))
+                assert q(e_sp) <= 1.1 * q(e_lib), (what, q(e_sp), q(e_lib))
+        assert nf.check_saturation() == 0
+    # a value beyond the fp16 range is clamped and counted, never silently
+    x = torch.randn(64, k, generator=gen).cuda()
+    x[5, 3] = 1.0e6
+    _lib.linear_f16x3(x, w, b)
+    with pytest.raises(nf.VcnfError):
+        nf.check_saturation()

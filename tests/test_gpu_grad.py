@@ -470,7 +470,24 @@ def test_resnet_training_uses_wgrad_kernel_and_matches_autograd(hip, ctx_dim):
     mine, launches = grads(8192)
     ref, none = grads(1 << 40)
     assert launches == 1 + 2 * 2 + (2 if ctx_dim else 0) + 1 and none == 0     # initial, 2 x 2 block layers, context layers, final
-    for a, b in zip(mine, ref):
+    # ``mine`` also runs the forward products (and the square layers' input gradients) on the split-half kernel
+    # (autograd.TRAIN_MATRIX_PATH): pre-activations differ from the library's at the 1e-7 level, so among the 4 M
+    # hidden units of this batch about one has a pre-activation at rounding level and takes the other side of its ReLU.
+    # That sample's contribution then moves between the two runs: its row of the input gradient, and ONE row (the
+    # unit's) of a weight gradient by a single sample's term (~1 % of the largest entry at this batch size).  Allowed:
+    # violations of the rounding-level bound in at most 2 % of a tensor's entries, none above 5 % of its largest entry.
+    for i, (a, b) in enumerate(zip(mine, ref)):
+        d = (a - b).abs()
+        bad = d > 2e-4 * float(b.abs().max()) + 1e-6
+        assert float(bad.float().mean()) <= 0.02 and float(d.max()) <= 0.05 * float(b.abs().max()) + 1e-6, \
+            (i, float(bad.float().mean()), float(d.max()), float(b.abs().max()))
+    # with the library's GEMMs on both sides (only the weight-gradient kernel differs) everything agrees to rounding
+    autograd.TRAIN_MATRIX_PATH = 'fp32'
+    try:
+        mine32, _ = grads(8192)
+    finally:
+        autograd.TRAIN_MATRIX_PATH = 'fp16x3'
+    for a, b in zip(mine32, ref):
         assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-6
 
 

@@ -98,6 +98,8 @@ PROTOTYPES = {
     "vcnf_rqs_layer_fused_supported": ([_I32, _I32, _I32, _I32, _I32, _I32, _I32], _INT),
     "vcnf_rqs_layer_fused_tile_rows": ([], _I32),
     "vcnf_rqs_layer_fused_small_batch_rows": ([_I64], _I64),
+    "vcnf_linear_f16x3_supported": ([_I32, _I32], _INT),
+    "vcnf_linear_f16x3_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I64, _I64, _P, _P], _INT),
     "vcnf_rqs_stack_fused_max_layers": ([], _I32),
     "vcnf_rqs_stack_fused_f32": ([_P, _P, _P, _P, _I64, ctypes.POINTER(RqsStackLayer), _I32, _I32, _I32, _I32, _I32, _I32,
                                   _I32, _I64, ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P, _P, _P], _INT),
@@ -873,6 +875,29 @@ def conv1x1_fused(x, wpack, c_out, in_bias=None, out_bias=None, in_slope=None, o
                                           _ptr(saturation_counter(dev)), _stream())
     _check(st, "vcnf_conv1x1_f16x3_f32")
     return out
+
+
+def linear_f16x3(x, weight, bias=None, input_grad=False):
+    """nn.Linear on the fp16 split-half matrix path at training batch sizes (csrc/linear_f16x3.hip): ``x @ weight.T +
+    bias`` for weight [out, in], or with ``input_grad`` the layer's input gradient ``x @ weight`` (x = the upstream
+    gradient [B, out]).  The weight is read in place (no packed copy).  Clamped values are counted in
+    saturation_counter (nf.check_saturation())."""
+    dev = require_device(x, weight, bias, allow_grad=True)
+    x, weight = x.detach().contiguous(), weight.detach().contiguous()
+    b, k = x.shape
+    n_out, n_in = weight.shape
+    if input_grad:
+        n, ldn, ldk = n_in, 1, n_in
+        assert k == n_out and bias is None
+    else:
+        n, ldn, ldk = n_out, n_in, 1
+        assert k == n_in
+    y = torch.empty(b, n, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("linear_f16x3"):
+        st = lib().vcnf_linear_f16x3_f32(_ptr(x), _ptr(weight), _ptr(bias.detach().contiguous() if bias is not None else None),
+                                         _ptr(y), b, int(k), int(n), int(ldn), int(ldk), _ptr(saturation_counter(dev)), _stream())
+    _check(st, "vcnf_linear_f16x3_f32")
+    return y
 
 
 _WGRAD_WS = {}        # workspace of the partial results per (device, stream): calls on one stream are ordered, calls on

@@ -265,6 +265,33 @@ class DiagGaussianSampleFn(torch.autograd.Function):
         g_eps = gz * sig - g_lp[:, None] * e
         return g_eps.reshape(eps.shape), gz.sum(0), (gz * sig * e - g_lp[:, None]).sum(0), None
 
+# Matrix path of the conditioner's dense layers on the training path at large batches: 'fp16x3' - forward products (and
+# the 128 -> 128 layers' input gradients) on csrc/linear_f16x3.hip (fp16 split-half operands, fp32 accumulation: error
+# against fp64 below the library's fp32 GEMM on every layer shape, 1.25-1.6x its speed on these shapes; values beyond
+# +-65504 are clamped and counted: nf.check_saturation()) - or 'fp32': the library's fp32 GEMMs everywhere.
+TRAIN_MATRIX_PATH = 'fp16x3'
+
+
+def _f16x3_ok(x, n_in, n_out):
+    return (TRAIN_MATRIX_PATH == 'fp16x3' and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+            and x.shape[0] >= WGRAD_MIN_BATCH and bool(_lib.lib().vcnf_linear_f16x3_supported(n_in, n_out)))
+
+
+def _fwd(x, weight, bias):
+    """x W^T + b: split-half kernel where it wins (every forward shape of the conditioner), library otherwise."""
+    if _f16x3_ok(x, weight.shape[1], weight.shape[0]):
+        return _lib.linear_f16x3(x, weight, bias)
+    return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+
+
+def _dgrad(gy, weight):
+    """gy W: split-half kernel for the square hidden layers (40 against 52 us at 131 072 x 128 x 128), library for the
+    narrow / very deep ones, where its tiling is as fast."""
+    if weight.shape[0] == weight.shape[1] and _f16x3_ok(gy, weight.shape[0], weight.shape[1]):
+        return _lib.linear_f16x3(gy, weight, None, input_grad=True)
+    return gy @ weight
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b whose weight / bias gradients come from csrc/linear_wgrad.hip (batch reduction split over the
     chip) instead of the library's output-tiled GEMM + column-sum kernel; forward and input gradient stay library GEMMs.
@@ -274,7 +301,7 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        return _fwd(x, weight, bias)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -282,7 +309,7 @@ class LinearFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = gy @ weight
+            gx = _dgrad(gy.contiguous(), weight)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw, gb = _lib.linear_wgrad(x, gy, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
             if not ctx.needs_input_grad[1]:
@@ -317,8 +344,8 @@ class ResBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, gate, w0, b0, w1, b1):
         t0 = torch.relu(h)
-        t1 = torch.relu_(torch.addmm(b0, t0, w0.t()))
-        c = torch.addmm(b1, t1, w1.t())
+        t1 = torch.relu_(_fwd(t0, w0, b0))
+        c = _fwd(t1, w1, b1)
         if gate is not None:
             out = _lib.resblock_op(0, h, c, gate)
             ctx.save_for_backward(t0, t1, w0, w1, c, gate)
@@ -339,9 +366,9 @@ class ResBlockFn(torch.autograd.Function):
             g_c, g_gate = g.contiguous(), None
         need = ctx.needs_input_grad
         gw1, gb1 = _wgrad_or_torch(t1, g_c) if (need[4] or need[5]) else (None, None)
-        g_a = _lib.resblock_op(2, g_c @ w1, t1)
+        g_a = _lib.resblock_op(2, _dgrad(g_c, w1), t1)
         gw0, gb0 = _wgrad_or_torch(t0, g_a) if (need[2] or need[3]) else (None, None)
-        g_h = _lib.resblock_op(3, g_a @ w0, t0, g) if need[0] else None
+        g_h = _lib.resblock_op(3, _dgrad(g_a, w0), t0, g) if need[0] else None
         return g_h, (g_gate if ctx.gated and need[1] else None), gw0, gb0, gw1, gb1
 
 
