@@ -356,6 +356,7 @@ def bench_train(args, device, rank, world, steps=None, warmup=None):
     dt = time.perf_counter() - t0
     _lib.EVENT_SINK = None
     assert torch.isfinite(loss)
+    assert nf.check_saturation(device) == 0, "a split-half training kernel clamped a value"
     durs = [a.elapsed_time(b) * 1e-3 for a, b, t in events if t == "linear_wgrad"]
     kern_s = sum(durs) / max(len(durs), 1)
     # algorithmic flop of the weight gradients of one layer's dense layers, averaged over the launches of a layer
@@ -367,7 +368,9 @@ def bench_train(args, device, rank, world, steps=None, warmup=None):
         "metric": "training samples/sec (Adam step on forward_kld), config C3", "value": round(B * steps / dt, 1),
         "unit": "samples/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
         "ms_per_step": round(1e3 * dt / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32 results; the conditioner's forward products and the square layers' input gradients on fp16x3 split "
+                 "operands (csrc/linear_f16x3.hip: error against fp64 below the library's fp32 GEMM), weight gradients on "
+                 "exact fp32 matrix instructions, remaining input gradients on the library's fp32 GEMMs", "data": "synthetic",
         "config": {"workload": "C3 model (D=64, 12 RQ-spline couplings, 8 bins, cond_dim=16), Adam step on forward_kld, "
                                "batch=%d" % B, "batch_per_gpu": B, "layers": LAYERS},
         "roofline": {"bound": "mfma", "kernel": "linear_wgrad_kernel", "achieved": round(per_launch / kern_s / 1e12, 1) if durs else 0.0,
@@ -376,8 +379,8 @@ def bench_train(args, device, rank, world, steps=None, warmup=None):
                      "launches": len(durs), "avg_launch_ms": round(kern_s * 1e3, 4),
                      "note": "weight / bias gradients of the conditioner's dense layers (exact fp32 matrix instructions, batch "
                              "reduction split over the chip), averaged over a layer's five shapes; the step also contains "
-                             "library GEMMs (forward, input gradients), the spline forward / VJP kernels and fused "
-                             "elementwise maps"}}
+                             "the split-half forward / input-gradient kernel, library GEMMs for the other input gradients, the "
+                             "spline forward / VJP kernels and fused elementwise maps"}}
     del model, opt, x, ctx
     torch.cuda.empty_cache()
     return out

@@ -335,6 +335,7 @@ def check_saturation(device="cuda", model=None):
     at the fp16 range since the last check (the reference is plain fp32 and does not clamp, nets/resnet.py:92-106).
     With ``model`` given and a non-zero count every fused RQS coupling of the model is switched to the exact
     fp32 matrix path (``fused_precision = 'fp32'``), so that re-running the evaluation gives reference results;
+    and the training path's dense layers go back to the library's fp32 GEMMs (``autograd.TRAIN_MATRIX_PATH``);
     without a model a non-zero count raises VcnfError."""
     c = saturation_counter(device)
     n = int(c.item())
@@ -343,6 +344,8 @@ def check_saturation(device="cuda", model=None):
         raise VcnfError("fp16 split-half matrix path clamped values at +-65504 in %d workgroup(s): "
                         "set fused_precision = 'fp32' on the couplings (or pass model=...) and re-run" % n)
     if n:
+        from . import autograd
+        autograd.TRAIN_MATRIX_PATH = "fp32"           # training path: the library's fp32 GEMMs (csrc/linear_f16x3.hip clamps too)
         for m in model.modules():
             if hasattr(m, "fused_precision"):
                 m.fused_precision = "fp32"
