@@ -369,15 +369,17 @@ def bench_train(args, device, rank, world, steps=None, warmup=None):
         "unit": "samples/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
         "ms_per_step": round(1e3 * dt / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 results; the conditioner's forward products and the square layers' input gradients on fp16x3 split "
-                 "operands (csrc/linear_f16x3.hip: error against fp64 below the library's fp32 GEMM), weight gradients on "
-                 "exact fp32 matrix instructions, remaining input gradients on the library's fp32 GEMMs", "data": "synthetic",
+                 "operands (csrc/linear_f16x3.hip), weight gradients likewise (csrc/linear_wgrad.hip, split-half form) - error "
+                 "against fp64 at or below the library's fp32 GEMM on every shape; remaining input gradients on the library's fp32 "
+                 "GEMMs", "data": "synthetic",
         "config": {"workload": "C3 model (D=64, 12 RQ-spline couplings, 8 bins, cond_dim=16), Adam step on forward_kld, "
                                "batch=%d" % B, "batch_per_gpu": B, "layers": LAYERS},
         "roofline": {"bound": "mfma", "kernel": "linear_wgrad_kernel", "achieved": round(per_launch / kern_s / 1e12, 1) if durs else 0.0,
                      "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": round(per_launch / kern_s / MFMA_F32_PEAK, 4) if durs else 0.0, "traffic": None,
                      "launches": len(durs), "avg_launch_ms": round(kern_s * 1e3, 4),
-                     "note": "weight / bias gradients of the conditioner's dense layers (exact fp32 matrix instructions, batch "
+                     "note": "weight / bias gradients of the conditioner's dense layers (split-half form: three f16 matrix "
+                             "instructions per product, priced here against the exact-fp32 peak its predecessor was bound by; batch "
                              "reduction split over the chip), averaged over a layer's five shapes; the step also contains "
                              "the split-half forward / input-gradient kernel, library GEMMs for the other input gradients, the "
                              "spline forward / VJP kernels and fused elementwise maps"}}

@@ -256,6 +256,13 @@ int64_t vcnf_linear_wgrad_slices(int64_t batch, int32_t in_features, int32_t out
 int vcnf_linear_wgrad_f32(const float* x, const float* dy, float* dw, float* db, float* workspace,
                           int64_t workspace_floats, int64_t batch, int32_t in_features, int32_t out_features,
                           int accumulate, void* stream);
+/* The same gradients with the partial products on the fp16 split-half matrix path (v_mfma_f32_32x32x16_f16, both
+ * operands split in registers, fp32 accumulation; arithmetic of VCNF_PREC_F16X3): the exact-fp32 kernel is bound by
+ * its matrix instructions, this one runs the 736-row last layer of config C3 in a third of the time.  Same workspace,
+ * same deterministic slice order.  Values beyond +-65504 are clamped and counted in sat_count (may be NULL). */
+int vcnf_linear_wgrad_f16x3_f32(const float* x, const float* dy, float* dw, float* db, float* workspace,
+                                int64_t workspace_floats, int64_t batch, int32_t in_features,
+                                int32_t out_features, int accumulate, int32_t* sat_count, void* stream);
 
 /* First two layers of the Glow conditioner in one launch (nets/cnn.py:20-52): y = act2(W2 act1(conv3x3(x; W1, padding 1)
  * + b1) + b2) with x [batch, c_in, height, width], 256 hidden and 256 output channels, act = LeakyReLU(slope); the

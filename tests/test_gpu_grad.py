@@ -439,6 +439,22 @@ def test_linear_wgrad_kernel(hip, n_in, n_out, b):
         assert got.shape == r64.shape and e_got <= 2.0 * e_ref + 1e-6 * float(r64.abs().max()), (what, e_got, e_ref)
     dw2, none = _lib.linear_wgrad(x, dy, want_bias=False)
     assert none is None and torch.equal(dw2, dw)                     # deterministic
+    # the split-half form of the same kernel (the training path's default): mean error against fp64 not above the
+    # fp32 GEMM's, deterministic, nothing clamped on these inputs; a value beyond the fp16 range is counted
+    nf.check_saturation()
+    dwh, dbh = _lib.linear_wgrad(x, dy, f16x3=True)
+    for got, r64, r32, what in ((dwh, w64, w32, "dW split-half"), (dbh, b64, b32, "db split-half")):
+        e_got, e_ref = (got.double() - r64).abs(), (r32.double() - r64).abs()
+        assert got.shape == r64.shape and float(e_got.mean()) <= 1.1 * float(e_ref.mean()) + 1e-7 * float(r64.abs().max()), \
+            (what, float(e_got.mean()), float(e_ref.mean()))
+        assert float(e_got.max()) <= 2.0 * float(e_ref.max()) + 1e-6 * float(r64.abs().max()), (what, float(e_got.max()))
+    assert torch.equal(_lib.linear_wgrad(x, dy, f16x3=True)[0], dwh)
+    assert nf.check_saturation() == 0
+    xb = x.clone()
+    xb[b // 2, 0] = 1.0e6
+    _lib.linear_wgrad(xb, dy, f16x3=True)
+    with pytest.raises(nf.VcnfError):
+        nf.check_saturation()
 
 
 @pytest.mark.parametrize("ctx_dim", [16, None])

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "vcnf_linear_wgrad_supported": ([_I32, _I32], _INT),
     "vcnf_linear_wgrad_slices": ([_I64, _I32, _I32], _I64),
     "vcnf_linear_wgrad_f32": ([_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _INT, _P], _INT),
+    "vcnf_linear_wgrad_f16x3_f32": ([_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _INT, _P, _P], _INT),
     "vcnf_conv3x3_1x1_supported": ([_I32, _I32, _I32], _INT),
     "vcnf_conv3x3_1x1_pack_floats": ([_I32], _I64),
     "vcnf_conv3x3_1x1_f16x3_f32": ([_P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _F32, _F32, _P, _P], _INT),
@@ -907,9 +908,10 @@ _WGRAD_WS = {}        # workspace of the partial results per (device, stream): c
                       # different streams (two models' backward passes, side streams) must not share it
 
 
-def linear_wgrad(x, dy, want_bias=True):
+def linear_wgrad(x, dy, want_bias=True, f16x3=False):
     """(dW [out, in], db [out] or None) of y = x W^T + b from x [B, in] and dy [B, out] (csrc/linear_wgrad.hip: the batch
-    reduction split over the chip, exact fp32 matrix instructions, deterministic)."""
+    reduction split over the chip, deterministic; exact fp32 matrix instructions, or with ``f16x3`` the fp16 split-half
+    matrix path - clamped values are counted in saturation_counter)."""
     dev = require_device(x, dy, allow_grad=True)
     x, dy = x.detach().contiguous(), dy.detach().contiguous()
     b, n_in = x.shape
@@ -927,8 +929,12 @@ def linear_wgrad(x, dy, want_bias=True):
     dw = torch.empty(n_out, n_in, dtype=torch.float32, device=dev)
     db = torch.empty(n_out, dtype=torch.float32, device=dev) if want_bias else None
     with torch.cuda.device(dev), _timed("linear_wgrad"):
-        st = lib().vcnf_linear_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), b, int(n_in),
-                                         int(n_out), 0, _stream())
+        if f16x3:
+            st = lib().vcnf_linear_wgrad_f16x3_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), b, int(n_in),
+                                                   int(n_out), 0, _ptr(saturation_counter(dev)), _stream())
+        else:
+            st = lib().vcnf_linear_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), b, int(n_in),
+                                             int(n_out), 0, _stream())
     _check(st, "vcnf_linear_wgrad_f32")
     return dw, db
 

@@ -265,10 +265,11 @@ class DiagGaussianSampleFn(torch.autograd.Function):
         g_eps = gz * sig - g_lp[:, None] * e
         return g_eps.reshape(eps.shape), gz.sum(0), (gz * sig * e - g_lp[:, None]).sum(0), None
 
-# Matrix path of the conditioner's dense layers on the training path at large batches: 'fp16x3' - forward products (and
-# the 128 -> 128 layers' input gradients) on csrc/linear_f16x3.hip (fp16 split-half operands, fp32 accumulation: error
-# against fp64 below the library's fp32 GEMM on every layer shape, 1.25-1.6x its speed on these shapes; values beyond
-# +-65504 are clamped and counted: nf.check_saturation()) - or 'fp32': the library's fp32 GEMMs everywhere.
+# Matrix path of the conditioner's dense layers on the training path at large batches: 'fp16x3' - forward products, the
+# 128 -> 128 layers' input gradients (csrc/linear_f16x3.hip) and the weight gradients (csrc/linear_wgrad.hip, split-half
+# form) on fp16 split-half operands with fp32 accumulation (error against fp64 below the library's fp32 GEMM on every
+# layer shape; values beyond +-65504 are clamped and counted: nf.check_saturation()) - or 'fp32': the library's fp32
+# GEMMs and the exact-fp32 weight-gradient kernel.
 TRAIN_MATRIX_PATH = 'fp16x3'
 
 
@@ -311,7 +312,8 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _dgrad(gy.contiguous(), weight)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = _lib.linear_wgrad(x, gy, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
+            gw, gb = _lib.linear_wgrad(x, gy, want_bias=ctx.has_bias and ctx.needs_input_grad[2],
+                                       f16x3=TRAIN_MATRIX_PATH == 'fp16x3')
             if not ctx.needs_input_grad[1]:
                 gw = None
         return gx, gw, gb
@@ -331,7 +333,7 @@ def linear(mod, x):
 
 def _wgrad_or_torch(x, gy, want_bias=True):
     if x.shape[0] >= WGRAD_MIN_BATCH and _lib.lib().vcnf_linear_wgrad_supported(x.shape[1], gy.shape[1]):
-        return _lib.linear_wgrad(x, gy, want_bias=want_bias)
+        return _lib.linear_wgrad(x, gy, want_bias=want_bias, f16x3=TRAIN_MATRIX_PATH == 'fp16x3')
     return gy.t() @ x, (gy.sum(0) if want_bias else None)
 
 
