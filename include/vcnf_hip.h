@@ -377,6 +377,24 @@ int vcnf_rqs_layer_fused_f32(const float* x, const float* context, float* y, flo
                              int ld_mode, float ld_sign, int32_t* bad_disc, int32_t* sat_count,
                              int32_t* redo_tiles, void* stream);
 
+/* A run of MaskedAffineFlow layers INCLUDING their MLP conditioners s, t = Linear(D, H) - LeakyReLU - Linear(H, D), and
+ * of the per-feature affine layers (AffineConstFlow / ActNorm) between them, in one launch: the loop body of
+ * NormalizingFlow.log_prob / sample (core.py:144-183) over the models of the reference's own drivers
+ * (/root/reference/run.py:58-68: K x [MaskedAffineFlow(b, t, s), ActNorm], D = 2 .. 15, 1024 - 2048 samples, fp64).
+ * Layer arithmetic: flows/affine/coupling.py:171-222 (non-finite s / t -> NaN), :22-61, nets/mlp.py:30-58.
+ * z, out [batch, features], features <= 16, hidden <= 64; logdet receives / accumulates ld_sign * the summed log|det|
+ * of the run (inverse: every layer inverted, in the order given).  table: DEVICE array of 12 int64 per layer in
+ * application order - [0] kind (0 masked affine, 1 per-feature), [1] hidden width, [2] LeakyReLU slope (bits of a
+ * double), [3] b [features]; [4..7] s: W1 [H, D], b1 [H], W2 [D, H], b2 [D] (0: no s); [8..11] t likewise;
+ * per-feature kind: [4] s [features] or 0, [5] t [features] or 0.  All pointers of the scalar type of the call. */
+int vcnf_masked_affine_stack_supported(int32_t features, int32_t hidden);
+int vcnf_masked_affine_stack_f32(const float* z, float* out, float* logdet, const int64_t* table,
+                                 int64_t batch, int32_t features, int32_t n_layers, int inverse,
+                                 int ld_mode, float ld_sign, void* stream);
+int vcnf_masked_affine_stack_f64(const double* z, double* out, double* logdet, const int64_t* table,
+                                 int64_t batch, int32_t features, int32_t n_layers, int inverse,
+                                 int ld_mode, double ld_sign, void* stream);
+
 /* Dense layer at training batch sizes on the fp16 split-half matrix path (csrc/linear_f16x3.hip):
  *   y[b, n] = sum_k x[b, k] * A[n, k] (+ bias[n]),  A[n, k] = w[n * ldn + k * ldk],  x [batch, k], y [batch, n]
  * = nn.Linear's forward (w = weight [n, k]: ldn = k, ldk = 1; nets/resnet.py:42-57, 92-106) and its input gradient

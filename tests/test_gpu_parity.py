@@ -1047,6 +1047,67 @@ def test_rqs_stack_is_range_safe_on_the_device(hip, sampling):
     _lib.bad_discriminant_counter("cuda").zero_()
 
 
+def _realnvp_like_reference_drivers(d, h, pairs, dtype, nets="st", leaky=0.0):
+    """K x [MaskedAffineFlow(b | 1 - b, t, s), ActNorm] with s, t = MLP([d, h, d]) - /root/reference/run.py:58-68."""
+    b = torch.tensor([1.0 if i % 2 == 0 else 0.0 for i in range(d)])
+    flows = []
+    for i in range(pairs):
+        s = nf.nets.MLP([d, h, d], leaky=leaky, init_zeros=True) if "s" in nets else None
+        t = nf.nets.MLP([d, h, d], leaky=leaky, init_zeros=True) if "t" in nets else None
+        flows += [nf.flows.MaskedAffineFlow(b if i % 2 == 0 else 1 - b, t, s), nf.flows.ActNorm(d)]
+    model = nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if ".net.2." in n:                        # the zero-initialised last layers: make the couplings do something
+                p.normal_(0.0, 0.1)
+    return model.to(dtype).cuda().eval()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["fp32", "fp64"])
+@pytest.mark.parametrize("d,h,nets,leaky", [(2, 16, "st", 0.0), (15, 30, "st", 0.0), (2, 4, "s", 0.1), (6, 64, "t", 0.0), (16, 33, "st", 0.2)])
+def test_masked_affine_stack_single_launch_matches_per_layer(hip, d, h, nets, leaky, dtype):
+    """The models of the reference's own drivers - K x [MaskedAffineFlow with MLP conditioners, ActNorm], fp32 and
+    .double() - evaluated by NormalizingFlow in ONE launch (csrc/masked_affine_stack.hip) against the per-layer path
+    (torch GEMMs + vcnf_masked_affine + vcnf_affine_const, itself pinned to the reference by fixtures G7 / G9):
+    log_prob, samples and their log-densities agree to rounding; ragged batches; a non-finite input gives the same NaN
+    pattern; an ActNorm that has not seen its first batch ends the run (and is initialised by the per-layer path)."""
+    from vcnf_amd import fused_masked
+    torch.manual_seed(10 * d + h)
+    model = _realnvp_like_reference_drivers(d, h, 6, dtype, nets, leaky)
+    tol = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=1e-11, atol=1e-11)
+    x0 = torch.randn(512, d, device="cuda", dtype=dtype)
+    with torch.no_grad():
+        assert fused_masked.plan(list(reversed(model.flows)), 0, x0) is None      # ActNorm not initialised: no run yet
+        model.log_prob(x0)                                                        # first batch: data-dependent init
+        for f in model.flows:
+            if isinstance(f, nf.flows.ActNorm):
+                f.s.add_(0.05 * torch.randn_like(f.s))
+                f.t.add_(0.05 * torch.randn_like(f.t))
+        plan = fused_masked.plan(list(reversed(model.flows)), 0, x0)
+        assert plan is not None and plan[0] == len(model.flows)
+    for B in (1, 17, 1024 + 3):
+        x, eps = torch.randn(B, d, device="cuda", dtype=dtype), torch.randn(B, d, device="cuda", dtype=dtype)
+        out = {}
+        for stacks in (True, False):
+            model.fuse_masked_stacks = stacks
+            with torch.no_grad():
+                out[stacks] = (model.log_prob(x),) + tuple(model.sample_from(eps))
+        model.fuse_masked_stacks = True
+        for a, b in zip(out[True], out[False]):
+            assert torch.isfinite(b).all() and torch.allclose(a, b, **tol), (B, float((a - b).abs().max()))
+    xb = torch.randn(40, d, device="cuda", dtype=dtype)
+    xb[7, 0] = float("inf")
+    res = []
+    for stacks in (True, False):
+        model.fuse_masked_stacks = stacks
+        with torch.no_grad():
+            res.append(model.log_prob(xb))
+    model.fuse_masked_stacks = True
+    assert torch.equal(torch.isnan(res[0]), torch.isnan(res[1])) and torch.equal(torch.isinf(res[0]), torch.isinf(res[1]))
+    ok = torch.isfinite(res[1])
+    assert torch.allclose(res[0][ok], res[1][ok], **tol)
+
+
 def test_data_mutation_needs_refresh_packed(hip):
     """the packed weight caches key on (data_ptr, _version); ``p.data`` edits do not bump _version.
     refresh_packed() (also run by train() / eval() / load_state_dict()) makes the fused kernel see them."""

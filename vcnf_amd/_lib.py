@@ -99,6 +99,9 @@ PROTOTYPES = {
     "vcnf_rqs_layer_fused_supported": ([_I32, _I32, _I32, _I32, _I32, _I32, _I32], _INT),
     "vcnf_rqs_layer_fused_tile_rows": ([], _I32),
     "vcnf_rqs_layer_fused_small_batch_rows": ([_I64], _I64),
+    "vcnf_masked_affine_stack_supported": ([_I32, _I32], _INT),
+    "vcnf_masked_affine_stack_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _INT, _INT, _F32, _P], _INT),
+    "vcnf_masked_affine_stack_f64": ([_P, _P, _P, _P, _I64, _I32, _I32, _INT, _INT, _F64, _P], _INT),
     "vcnf_linear_f16x3_supported": ([_I32, _I32], _INT),
     "vcnf_linear_f16x3_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I64, _I64, _P, _P], _INT),
     "vcnf_rqs_stack_fused_max_layers": ([], _I32),
@@ -879,6 +882,24 @@ def conv1x1_fused(x, wpack, c_out, in_bias=None, out_bias=None, in_slope=None, o
                                           _ptr(saturation_counter(dev)), _stream())
     _check(st, "vcnf_conv1x1_f16x3_f32")
     return out
+
+
+def masked_affine_stack(z, table, n_layers, inverse, logdet=None, sign=1.0):
+    """A run of MaskedAffineFlow (+ MLP conditioners) and per-feature affine layers in one launch
+    (csrc/masked_affine_stack.hip); ``table``: device int64 [n_layers, 12] as described in include/vcnf_hip.h."""
+    dev = require_device(z, logdet, f64=True)
+    z = z.contiguous()
+    b, d = z.shape
+    out = torch.empty_like(z)
+    mode = LD_ACCUM
+    if logdet is None:
+        logdet = torch.empty(b, dtype=z.dtype, device=dev)
+        mode = LD_STORE
+    with torch.cuda.device(dev):
+        st = getattr(lib(), "vcnf_masked_affine_stack" + _sfx(z))(_ptr(z), _ptr(out), _ptr(logdet), _ptr(table), b, int(d),
+                                                                  int(n_layers), int(bool(inverse)), mode, float(sign), _stream())
+    _check(st, "vcnf_masked_affine_stack" + _sfx(z))
+    return out, logdet
 
 
 def linear_f16x3(x, weight, bias=None, input_grad=False):

@@ -12,7 +12,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libvcnf_hip.so")
 SOURCES = ["rqs_kernels.hip", "affine_kernels.hip", "fused_layer.hip",
            "fused_layer_v6.hip", "fused_affine.hip", "fused_final.hip", "resnet_trunk.hip", "channel_mix.hip", "conv1x1.hip", "conv3x3_1x1.hip", "linear_wgrad.hip", "resblock_ops.hip",
-           "rqs_backward.hip", "gemm_probe.hip", "rqs_f64.hip", "linear_f16x3.hip"]
+           "rqs_backward.hip", "gemm_probe.hip", "rqs_f64.hip", "linear_f16x3.hip", "masked_affine_stack.hip"]
 # (source, extra flags, object name): fused_layer_v6.hip is compiled once per number of residual blocks.  The two
 # kernels whose spline code runs beside matrix instructions are built without SLP vectorisation: packed-f32 vector
 # instructions starve beside the partner wave's matrix instructions (profiles/r02_spline_eval_microbench.md)

@@ -16,8 +16,8 @@ the AttributeError the reference has at this HEAD.
 import torch
 from torch import nn
 
-from .flows.affine.coupling import AffineCouplingBlock, _scale_code
-from . import fused_affine, fused
+from .flows.affine.coupling import AffineCouplingBlock, MaskedAffineFlow, AffineConstFlow, _scale_code
+from . import fused_affine, fused, fused_masked
 from .flows.mixing import Permute
 from .flows.neural_spline.wrapper import CoupledRationalQuadraticSpline
 from .fused import refresh_packed
@@ -51,6 +51,7 @@ class NormalizingFlow(_PackedWeightsMixin, nn.Module):
         self.categoricals = None
         self.fuse_affine_stacks = True           # runs of one-kernel affine layers in a single launch (fused_affine.run_stack)
         self.fuse_rqs_stacks = True              # runs of one-kernel RQS layers in a single launch at small batches (fused.run_stack)
+        self.fuse_masked_stacks = True           # runs of MaskedAffineFlow (+ MLP conditioners) / ActNorm layers in a single launch
 
     # ------------------------------------------------------------ density
     def log_prob(self, x, context=None):
@@ -76,6 +77,13 @@ class NormalizingFlow(_PackedWeightsMixin, nn.Module):
                     core_ = steps[0][0].flows[1]
                     z = fused_affine.run_stack(steps, trailing, z, _scale_code(core_.scale, core_.scale_map), True,
                                                log_q, 1.0)[0]
+                    continue
+            # a run of MaskedAffineFlow layers with MLP conditioners / per-feature affine layers is ONE launch
+            if self.fuse_masked_stacks and isinstance(flow, (MaskedAffineFlow, AffineConstFlow)):
+                plan = fused_masked.cached_plan(self, order, i, z)
+                if plan is not None:
+                    resume, steps = plan
+                    z = fused_masked.run(steps, z, True, log_q, 1.0)[0]
                     continue
             # a run of one-kernel RQS coupling layers at a small batch is ONE launch (the tile stays in LDS)
             if self.fuse_rqs_stacks and type(flow) is CoupledRationalQuadraticSpline:
@@ -130,6 +138,12 @@ class NormalizingFlow(_PackedWeightsMixin, nn.Module):
                     core_ = steps[0][0].flows[1]
                     z = fused_affine.run_stack(steps, trailing, z, _scale_code(core_.scale, core_.scale_map), False,
                                                log_q, -1.0)[0]
+                    continue
+            if self.fuse_masked_stacks and isinstance(flow, (MaskedAffineFlow, AffineConstFlow)):
+                plan = fused_masked.cached_plan(self, order, i, z)
+                if plan is not None:
+                    resume, steps = plan
+                    z = fused_masked.run(steps, z, False, log_q, -1.0)[0]
                     continue
             if self.fuse_rqs_stacks and type(flow) is CoupledRationalQuadraticSpline:
                 plan = fused.cached_plan_stack(self, order, i, z, context)

@@ -25,12 +25,23 @@ class ActNorm(AffineConstFlow):
                 self.t.data = (-mean * torch.exp(self.s)).data
             self.data_dep_init_done = torch.ones_like(self.data_dep_init_done)
 
+    def _initialised(self):
+        """normalization.py:29 / :40 test the device flag on every call (a host synchronisation per layer and call,
+        and not capturable into a HIP graph).  The flag only ever goes from 0 to 1, so the first positive answer is
+        remembered on the host; load_state_dict() / refresh_packed() forget it."""
+        if self.__dict__.get('_init_done_host', False):
+            return True
+        done = bool(self.data_dep_init_done > 0.)
+        if done:
+            self.__dict__['_init_done_host'] = True
+        return done
+
     def forward(self, z):
-        if not self.data_dep_init_done > 0.:
+        if not self._initialised():
             self._init_from(z, inverse=False)
         return super().forward(z)
 
     def inverse(self, z):
-        if not self.data_dep_init_done > 0.:
+        if not self._initialised():
             self._init_from(z, inverse=True)
         return super().inverse(z)

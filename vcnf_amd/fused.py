@@ -396,6 +396,9 @@ def refresh_packed(module):
     for m in module.modules():
         d = m.__dict__
         d.pop('_fused_slots', None)
+        d.pop('_init_done_host', None)              # ActNorm: re-read the device flag (a loaded state dict may reset it)
+        d.pop('_masked_stack', None)
+        d.pop('_masked_stack_plans', None)
         d.pop('_fused_rqs_stack', None)
         d.pop('_rqs_stack_plans', None)
         if isinstance(d.get('_fused_pack'), dict):
