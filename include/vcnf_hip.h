@@ -395,6 +395,20 @@ int vcnf_masked_affine_stack_f64(const double* z, double* out, double* logdet, c
                                  int64_t batch, int32_t features, int32_t n_layers, int inverse,
                                  int ld_mode, double ld_sign, void* stream);
 
+/* Vector-Jacobian product of vcnf_masked_affine_stack_* (training through these layers: core.py:30-141 over
+ * coupling.py:171-222 / :22-61 / mlp.py:30-58).  z_out = the forward call's output (nothing else is kept: the
+ * kernel walks the layers backwards and rebuilds every layer's input from its output), g_out / g_logdet = upstream
+ * gradients of the output and of the run's summed log|det| (g_logdet may be NULL), g_in = gradient of the run's
+ * input.  Parameter gradients are ADDED (hardware floating-point atomics, batch order not fixed) into the flat
+ * buffer `grads`, zeroed by the caller; grad_offsets[l] = element offset of layer l's block - masked affine:
+ * [W1s | b1s | W2s | b2s | W1t | b1t | W2t | b2t] (absent conditioners take no room), per-feature: [s | t]. */
+int vcnf_masked_affine_stack_bwd_f32(const float* z_out, const float* g_out, const float* g_logdet, float* g_in,
+                                     float* grads, const int64_t* table, const int64_t* grad_offsets,
+                                     int64_t batch, int32_t features, int32_t n_layers, int inverse, void* stream);
+int vcnf_masked_affine_stack_bwd_f64(const double* z_out, const double* g_out, const double* g_logdet, double* g_in,
+                                     double* grads, const int64_t* table, const int64_t* grad_offsets,
+                                     int64_t batch, int32_t features, int32_t n_layers, int inverse, void* stream);
+
 /* Dense layer at training batch sizes on the fp16 split-half matrix path (csrc/linear_f16x3.hip):
  *   y[b, n] = sum_k x[b, k] * A[n, k] (+ bias[n]),  A[n, k] = w[n * ldn + k * ldk],  x [batch, k], y [batch, n]
  * = nn.Linear's forward (w = weight [n, k]: ldn = k, ldk = 1; nets/resnet.py:42-57, 92-106) and its input gradient

@@ -365,6 +365,60 @@ def test_graphed_train_step_matches_eager_steps(hip):
     nf.check_discriminant()
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["fp64", "fp32"])
+@pytest.mark.parametrize("d,h,nets,leaky", [(2, 16, "st", 0.0), (15, 30, "st", 0.0), (3, 8, "s", 0.1), (6, 40, "t", 0.0)])
+def test_masked_affine_stack_vjp_matches_per_layer_autograd(hip, d, h, nets, leaky, dtype):
+    """Training through the reference drivers' own models (K x [MaskedAffineFlow with MLP conditioners, ActNorm],
+    /root/reference/run.py:58-68): the run is ONE autograd node (fused_masked.MaskedStackFn) whose backward is one
+    launch of vcnf_masked_affine_stack_bwd_* - it keeps only the run's output and rebuilds every layer's input from
+    it.  Against autograd over the per-layer path (torch GEMMs + the closed-form VJPs of vcnf_amd.autograd, themselves
+    checked against the oracle / the reference's own autograd, G23): gradients of every parameter and of the input, for
+    forward_kld (density direction) and for a loss on samples and their log-density (sampling direction)."""
+    b = torch.tensor([1.0 if i % 2 == 0 else 0.0 for i in range(d)])
+    torch.manual_seed(31 * d + h)
+    flows = []
+    for i in range(5):
+        s = nf.nets.MLP([d, h, d], leaky=leaky, init_zeros=True) if "s" in nets else None
+        t = nf.nets.MLP([d, h, d], leaky=leaky, init_zeros=True) if "t" in nets else None
+        flows += [nf.flows.MaskedAffineFlow(b if i % 2 == 0 else 1 - b, t, s), nf.flows.ActNorm(d)]
+    model = nf.NormalizingFlow(nf.distributions.DiagGaussian(d), flows)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if ".net.2." in n:
+                p.normal_(0.0, 0.5 / h ** 0.5)
+    model = model.to(dtype).cuda()
+    B = 300 + 7
+    x0 = torch.randn(B, d, device="cuda", dtype=dtype)
+    with torch.no_grad():
+        model.log_prob(x0)                                     # ActNorm initialisation
+        for f in model.flows:
+            if isinstance(f, nf.flows.ActNorm):
+                f.s.add_(0.05 * torch.randn_like(f.s))
+    w = torch.randn(B, d, device="cuda", dtype=dtype)
+
+    def grads(stacks, which):
+        model.fuse_masked_stacks = stacks
+        model.zero_grad(set_to_none=True)
+        xin = x0.clone().requires_grad_(True)
+        if which == "density":
+            loss = model.forward_kld(xin) + 0.0
+        else:
+            z, lq = model.sample_from(xin)
+            loss = (z * w).sum() / B + lq.mean()
+        loss.backward()
+        return [float(loss.detach())], [xin.grad] + [p.grad.clone() for p in model.parameters()]
+    tol = 1e-9 if dtype == torch.float64 else 3e-4
+    for which in ("density", "sampling"):
+        l1, g1 = grads(True, which)
+        l0, g0 = grads(False, which)
+        assert np.isfinite(l0[0]) and abs(l1[0] - l0[0]) <= tol * (1 + abs(l0[0]))
+        for i, (a, b_) in enumerate(zip(g1, g0)):
+            assert a.shape == b_.shape
+            err, scale = float((a - b_).abs().max()), float(b_.abs().max())
+            assert err <= tol * (scale + 1e-3), (which, i, err, scale)
+    model.fuse_masked_stacks = True
+
+
 def test_nsf_stack_with_lu_linear_permute_trains(hip):
     """The neural-spline-flow layout of arXiv 1906.04032 (spline coupling + LULinearPermute per
     layer): gradients against the oracle stack in fp64, then a few optimiser steps."""

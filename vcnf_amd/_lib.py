@@ -102,6 +102,8 @@ PROTOTYPES = {
     "vcnf_masked_affine_stack_supported": ([_I32, _I32], _INT),
     "vcnf_masked_affine_stack_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _INT, _INT, _F32, _P], _INT),
     "vcnf_masked_affine_stack_f64": ([_P, _P, _P, _P, _I64, _I32, _I32, _INT, _INT, _F64, _P], _INT),
+    "vcnf_masked_affine_stack_bwd_f32": ([_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _INT, _P], _INT),
+    "vcnf_masked_affine_stack_bwd_f64": ([_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _INT, _P], _INT),
     "vcnf_linear_f16x3_supported": ([_I32, _I32], _INT),
     "vcnf_linear_f16x3_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I64, _I64, _P, _P], _INT),
     "vcnf_rqs_stack_fused_max_layers": ([], _I32),
@@ -900,6 +902,23 @@ def masked_affine_stack(z, table, n_layers, inverse, logdet=None, sign=1.0):
                                                                   int(n_layers), int(bool(inverse)), mode, float(sign), _stream())
     _check(st, "vcnf_masked_affine_stack" + _sfx(z))
     return out, logdet
+
+
+def masked_affine_stack_bwd(z_out, g_out, g_ld, table, goff, n_layers, n_grad, inverse):
+    """VJP of masked_affine_stack: (gradient of the run's input, flat parameter-gradient buffer [n_grad])."""
+    dev = require_device(z_out, g_out, g_ld, f64=True, allow_grad=True)
+    z_out, g_out = z_out.contiguous(), g_out.contiguous()
+    if g_ld is not None:
+        g_ld = g_ld.contiguous()
+    b, d = z_out.shape
+    g_in = torch.empty_like(z_out)
+    grads = torch.zeros(n_grad, dtype=z_out.dtype, device=dev)
+    with torch.cuda.device(dev):
+        st = getattr(lib(), "vcnf_masked_affine_stack_bwd" + _sfx(z_out))(
+            _ptr(z_out), _ptr(g_out), _ptr(g_ld), _ptr(g_in), _ptr(grads), _ptr(table), _ptr(goff), b, int(d), int(n_layers),
+            int(bool(inverse)), _stream())
+    _check(st, "vcnf_masked_affine_stack_bwd" + _sfx(z_out))
+    return g_in, grads
 
 
 def linear_f16x3(x, weight, bias=None, input_grad=False):

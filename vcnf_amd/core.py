@@ -83,7 +83,7 @@ class NormalizingFlow(_PackedWeightsMixin, nn.Module):
                 plan = fused_masked.cached_plan(self, order, i, z)
                 if plan is not None:
                     resume, steps = plan
-                    z = fused_masked.run(steps, z, True, log_q, 1.0)[0]
+                    z, log_q = fused_masked.run(steps, z, True, log_q, 1.0)       # (a new log_q when autograd records)
                     continue
             # a run of one-kernel RQS coupling layers at a small batch is ONE launch (the tile stays in LDS)
             if self.fuse_rqs_stacks and type(flow) is CoupledRationalQuadraticSpline:
@@ -143,7 +143,7 @@ class NormalizingFlow(_PackedWeightsMixin, nn.Module):
                 plan = fused_masked.cached_plan(self, order, i, z)
                 if plan is not None:
                     resume, steps = plan
-                    z = fused_masked.run(steps, z, False, log_q, -1.0)[0]
+                    z, log_q = fused_masked.run(steps, z, False, log_q, -1.0)
                     continue
             if self.fuse_rqs_stacks and type(flow) is CoupledRationalQuadraticSpline:
                 plan = fused.cached_plan_stack(self, order, i, z, context)

@@ -7,7 +7,9 @@ per (coupling, ActNorm) pair.
 ``plan`` finds the longest run a launch covers, ``run`` builds (and caches) the device table of parameter addresses the
 kernel walks.  Anything outside the kernel's family - conditioners that are not Linear-LeakyReLU-Linear, more than 16
 features or 64 hidden units, 4-D inputs, a gradient being required, an ActNorm that has not seen its first batch yet -
-ends the run and takes the per-layer path.
+ends the run and takes the per-layer path.  Training goes through the same launch: ``MaskedStackFn`` is the run as one
+autograd node whose backward is ONE launch of the VJP kernel (it keeps only the run's output and rebuilds every layer's
+input from its output - coupling layers are invertible).
 """
 import struct
 
@@ -84,11 +86,9 @@ def _layer_tensors(flow, kind):
 
 def plan(order, start, z):
     """Longest run order[start:end] of at least two layers one launch evaluates, or None: [B, D] inputs on the device
-    in fp32 or fp64, D <= 16, no gradient required, every layer in the kernel's family and of the inputs' dtype."""
+    in fp32 or fp64, D <= 16, every layer in the kernel's family and of the inputs' dtype.  With autograd recording the
+    run is one differentiable node (MaskedStackFn: one more launch for the whole backward pass)."""
     if z.dim() != 2 or not z.is_cuda or z.dtype not in (torch.float32, torch.float64) or z.shape[1] > 16:
-        return None
-    grad = torch.is_grad_enabled()
-    if grad and z.requires_grad:
         return None
     run = []
     for flow in order[start:start + MAX_LAYERS]:
@@ -96,7 +96,7 @@ def plan(order, start, z):
         if desc is None:
             break
         tens = [t for t in desc[3] if t is not None]
-        if any(t.dtype != z.dtype or t.device != z.device for t in tens) or (grad and any(t.requires_grad for t in tens)):
+        if any(t.dtype != z.dtype or t.device != z.device for t in tens):
             break
         run.append((flow, desc))
     if len(run) < 2:
@@ -157,4 +157,47 @@ def run(steps, z, inverse, log_q, sign):
         cache['key'] = key
         cache['table'] = torch.tensor(rows, dtype=torch.int64, device=z.device)
         cache['n'] = len(rows)
+    if torch.is_grad_enabled() and (z.requires_grad or any(t.requires_grad for t in tens)):
+        if 'goff' not in cache or cache.get('goff_key') != key:
+            offs, n = [], 0
+            for flow, (kind, h, slope, _) in steps:
+                offs.append(n)
+                n += sum(t.numel() for t in _layer_tensors(flow, kind)[1:] if t is not None)
+            cache['goff'] = torch.tensor(offs, dtype=torch.int64, device=z.device)
+            cache['n_grad'] = n
+            cache['goff_key'] = key
+        params = [t for flow, (kind, h, slope, _) in steps for t in _layer_tensors(flow, kind)[1:] if t is not None]
+        out, ld = MaskedStackFn.apply(z, cache['table'], cache['goff'], cache['n'], cache['n_grad'], bool(inverse), *params)
+        if log_q is not None:
+            return out, log_q + sign * ld
+        return out, (ld if sign == 1.0 else sign * ld)
     return _lib.masked_affine_stack(z, cache['table'], cache['n'], inverse, logdet=log_q, sign=sign)
+
+
+class MaskedStackFn(torch.autograd.Function):
+    """(out, log_det [B]) of a planned run as ONE autograd node: forward = vcnf_masked_affine_stack_*, backward =
+    vcnf_masked_affine_stack_bwd_* (keeps only ``out``).  ``params``: the run's parameters in table order (the mask
+    buffers are not differentiated); their gradients come back as views of one flat buffer."""
+
+    @staticmethod
+    def forward(ctx, z, table, goff, n_layers, n_grad, inverse, *params):
+        with torch.no_grad():
+            out, ld = _lib.masked_affine_stack(z.detach(), table, n_layers, inverse)
+        ctx.save_for_backward(out, table, goff)
+        ctx.meta = (n_layers, n_grad, inverse, [tuple(p.shape) for p in params], z.requires_grad)
+        return out, ld
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_out, g_ld):
+        out, table, goff = ctx.saved_tensors
+        n_layers, n_grad, inverse, shapes, need_z = ctx.meta
+        g_in, flat = _lib.masked_affine_stack_bwd(out, g_out, g_ld, table, goff, n_layers, n_grad, inverse)
+        grads, at = [], 0
+        for shp in shapes:
+            n = 1
+            for v in shp:
+                n *= v
+            grads.append(flat[at:at + n].view(shp))
+            at += n
+        return (g_in if need_z else None, None, None, None, None, None) + tuple(grads)
