@@ -109,11 +109,9 @@ def _stamp(flow):
 
 
 def cached_plan(owner, order, start, z):
-    """``plan`` memoised on the calling model for evaluations without autograd: 64 layers of checks cost more than the
-    launch they save.  A cached plan is reused while the run's modules (and their conditioner sub-modules) are the same
-    objects; shape, dtype and device of the inputs are part of the key."""
-    if torch.is_grad_enabled():
-        return plan(order, start, z)
+    """``plan`` memoised on the calling model (the plan does not depend on whether autograd records): 64 layers of
+    checks cost more than the launch they save.  A cached plan is reused while the run's modules (and their conditioner
+    sub-modules) are the same objects; shape, dtype and device of the inputs are part of the key."""
     if z.dim() != 2:
         return None
     key = (start, len(order), id(order[start]), z.shape[1], z.dtype, str(z.device))

@@ -90,7 +90,8 @@ class GraphedTrainStep:
     path takes device pointers and sizes only, never synchronises and allocates through PyTorch's caching allocator,
     so the whole step records into one graph (the standard whole-network capture recipe of ``torch.cuda.graphs``).
 
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True, fused=True)   # fused: ONE kernel for all
+                                                    # parameters (foreach-Adam is ~650 tiny launches on a 450-tensor model)
         step = nf.GraphedTrainStep(model, opt, batch=2048, context_features=16)
         for x, ctx in loader:
             loss = step(x, ctx)              # device scalar of THIS step; read it (``float(loss)``) only when needed
