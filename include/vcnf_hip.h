@@ -259,10 +259,12 @@ int vcnf_linear_wgrad_f32(const float* x, const float* dy, float* dw, float* db,
 /* The same gradients with the partial products on the fp16 split-half matrix path (v_mfma_f32_32x32x16_f16, both
  * operands split in registers, fp32 accumulation; arithmetic of VCNF_PREC_F16X3): the exact-fp32 kernel is bound by
  * its matrix instructions, this one runs the 736-row last layer of config C3 in a third of the time.  Same workspace,
- * same deterministic slice order.  Values beyond +-65504 are clamped and counted in sat_count (may be NULL). */
+ * same deterministic slice order.  relu_input: the layer's input is relu(x) (applied on load).  Values beyond +-65504
+ * are clamped and counted in sat_count (may be NULL). */
 int vcnf_linear_wgrad_f16x3_f32(const float* x, const float* dy, float* dw, float* db, float* workspace,
                                 int64_t workspace_floats, int64_t batch, int32_t in_features,
-                                int32_t out_features, int accumulate, int32_t* sat_count, void* stream);
+                                int32_t out_features, int accumulate, int relu_input, int32_t* sat_count,
+                                void* stream);
 
 /* First two layers of the Glow conditioner in one launch (nets/cnn.py:20-52): y = act2(W2 act1(conv3x3(x; W1, padding 1)
  * + b1) + b2) with x [batch, c_in, height, width], 256 hidden and 256 output channels, act = LeakyReLU(slope); the
@@ -415,11 +417,14 @@ int vcnf_masked_affine_stack_bwd_f64(const double* z_out, const double* g_out, c
  * g_x = g_y W (w = weight [k, n]: ldn = 1, ldk = n), i.e. what autograd computes for the conditioner's dense layers
  * in NormalizingFlow.forward_kld (core.py:30-65).  The weights are read in their natural fp32 layout and split in
  * registers; arithmetic as VCNF_PREC_F16X3 of vcnf_rqs_layer_fused_f32 (lo*lo kept for k <= 48).  k % 16 == 0,
- * n % 4 == 0, and n <= 128 when k > 128.  x, y 16-byte aligned.  Values beyond +-65504 (or NaN inputs) are clamped
- * and counted in sat_count (device int32, may be NULL) once per 64-sample tile. */
+ * n % 4 == 0, and n <= 128 when k > 128.  x, y 16-byte aligned.  relu_input / relu_output: ReLU applied to x while it
+ * is read / to y before it is stored (the residual block's activations, nets/resnet.py:42, :46, without their own
+ * passes over memory).  Values beyond +-65504 (or NaN inputs) are clamped and counted in sat_count (device int32, may
+ * be NULL) once per 64-sample tile. */
 int vcnf_linear_f16x3_supported(int32_t k, int32_t n);
 int vcnf_linear_f16x3_f32(const float* x, const float* w, const float* bias, float* y, int64_t batch,
-                          int32_t k, int32_t n, int64_t ldn, int64_t ldk, int32_t* sat_count, void* stream);
+                          int32_t k, int32_t n, int64_t ldn, int64_t ldk, int relu_input, int relu_output,
+                          int32_t* sat_count, void* stream);
 
 /* A run of n_layers (<= vcnf_rqs_stack_fused_max_layers() = 16) RQS coupling layers of ONE shape and one spline
  * configuration in a single launch: the body of NormalizingFlow.log_prob / sample over consecutive

@@ -204,6 +204,12 @@ def test_training_linear_f16x3_error_not_above_library_fp32(hip, k, n):
                 q = lambda e: float(e.flatten()[::3].quantile(0.999))
                 assert q(e_sp) <= 1.1 * q(e_lib), (what, q(e_sp), q(e_lib))
         assert nf.check_saturation() == 0
+    # ReLU on the input while it is read / on the result before it is stored (the residual block's activations ride on the
+    # kernel): exactly the composition with torch.relu
+    xr = torch.randn(200, k, generator=gen).cuda()
+    assert torch.equal(_lib.linear_f16x3(xr, w, b, relu_in=True), _lib.linear_f16x3(torch.relu(xr), w, b))
+    assert torch.equal(_lib.linear_f16x3(xr, w, b, relu_out=True), torch.relu(_lib.linear_f16x3(xr, w, b)))
+    nf.check_saturation()
     # a value beyond the fp16 range is clamped and counted, never silently
     x = torch.randn(64, k, generator=gen).cuda()
     x[5, 3] = 1.0e6

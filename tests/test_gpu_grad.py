@@ -503,6 +503,8 @@ def test_linear_wgrad_kernel(hip, n_in, n_out, b):
             (what, float(e_got.mean()), float(e_ref.mean()))
         assert float(e_got.max()) <= 2.0 * float(e_ref.max()) + 1e-6 * float(r64.abs().max()), (what, float(e_got.max()))
     assert torch.equal(_lib.linear_wgrad(x, dy, f16x3=True)[0], dwh)
+    # ReLU on the layer input applied on load: the same values as materialising relu(x) first
+    assert torch.equal(_lib.linear_wgrad(x, dy, f16x3=True, relu_x=True)[0], _lib.linear_wgrad(torch.relu(x), dy, f16x3=True)[0])
     assert nf.check_saturation() == 0
     xb = x.clone()
     xb[b // 2, 0] = 1.0e6

@@ -79,7 +79,7 @@ PROTOTYPES = {
     "vcnf_linear_wgrad_supported": ([_I32, _I32], _INT),
     "vcnf_linear_wgrad_slices": ([_I64, _I32, _I32], _I64),
     "vcnf_linear_wgrad_f32": ([_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _INT, _P], _INT),
-    "vcnf_linear_wgrad_f16x3_f32": ([_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _INT, _P, _P], _INT),
+    "vcnf_linear_wgrad_f16x3_f32": ([_P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _INT, _INT, _P, _P], _INT),
     "vcnf_conv3x3_1x1_supported": ([_I32, _I32, _I32], _INT),
     "vcnf_conv3x3_1x1_pack_floats": ([_I32], _I64),
     "vcnf_conv3x3_1x1_f16x3_f32": ([_P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _F32, _F32, _P, _P], _INT),
@@ -105,7 +105,7 @@ PROTOTYPES = {
     "vcnf_masked_affine_stack_bwd_f32": ([_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _INT, _P], _INT),
     "vcnf_masked_affine_stack_bwd_f64": ([_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _INT, _P], _INT),
     "vcnf_linear_f16x3_supported": ([_I32, _I32], _INT),
-    "vcnf_linear_f16x3_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I64, _I64, _P, _P], _INT),
+    "vcnf_linear_f16x3_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I64, _I64, _INT, _INT, _P, _P], _INT),
     "vcnf_rqs_stack_fused_max_layers": ([], _I32),
     "vcnf_rqs_stack_fused_f32": ([_P, _P, _P, _P, _I64, ctypes.POINTER(RqsStackLayer), _I32, _I32, _I32, _I32, _I32, _I32,
                                   _I32, _I64, ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P, _P, _P], _INT),
@@ -921,11 +921,11 @@ def masked_affine_stack_bwd(z_out, g_out, g_ld, table, goff, n_layers, n_grad, i
     return g_in, grads
 
 
-def linear_f16x3(x, weight, bias=None, input_grad=False):
+def linear_f16x3(x, weight, bias=None, input_grad=False, relu_in=False, relu_out=False):
     """nn.Linear on the fp16 split-half matrix path at training batch sizes (csrc/linear_f16x3.hip): ``x @ weight.T +
     bias`` for weight [out, in], or with ``input_grad`` the layer's input gradient ``x @ weight`` (x = the upstream
-    gradient [B, out]).  The weight is read in place (no packed copy).  Clamped values are counted in
-    saturation_counter (nf.check_saturation())."""
+    gradient [B, out]).  The weight is read in place (no packed copy); ``relu_in`` / ``relu_out`` apply ReLU to x as it is
+    read / to the result before it is stored.  Clamped values are counted in saturation_counter (nf.check_saturation())."""
     dev = require_device(x, weight, bias, allow_grad=True)
     x, weight = x.detach().contiguous(), weight.detach().contiguous()
     b, k = x.shape
@@ -939,7 +939,8 @@ def linear_f16x3(x, weight, bias=None, input_grad=False):
     y = torch.empty(b, n, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), _timed("linear_f16x3"):
         st = lib().vcnf_linear_f16x3_f32(_ptr(x), _ptr(weight), _ptr(bias.detach().contiguous() if bias is not None else None),
-                                         _ptr(y), b, int(k), int(n), int(ldn), int(ldk), _ptr(saturation_counter(dev)), _stream())
+                                         _ptr(y), b, int(k), int(n), int(ldn), int(ldk), int(bool(relu_in)), int(bool(relu_out)),
+                                         _ptr(saturation_counter(dev)), _stream())
     _check(st, "vcnf_linear_f16x3_f32")
     return y
 
@@ -948,12 +949,14 @@ _WGRAD_WS = {}        # workspace of the partial results per (device, stream): c
                       # different streams (two models' backward passes, side streams) must not share it
 
 
-def linear_wgrad(x, dy, want_bias=True, f16x3=False):
+def linear_wgrad(x, dy, want_bias=True, f16x3=False, relu_x=False):
     """(dW [out, in], db [out] or None) of y = x W^T + b from x [B, in] and dy [B, out] (csrc/linear_wgrad.hip: the batch
     reduction split over the chip, deterministic; exact fp32 matrix instructions, or with ``f16x3`` the fp16 split-half
     matrix path - clamped values are counted in saturation_counter)."""
     dev = require_device(x, dy, allow_grad=True)
     x, dy = x.detach().contiguous(), dy.detach().contiguous()
+    if relu_x and not f16x3:
+        x = torch.relu(x)
     b, n_in = x.shape
     n_out = dy.shape[1]
     slices = int(lib().vcnf_linear_wgrad_slices(b, n_in, n_out))
@@ -971,7 +974,7 @@ def linear_wgrad(x, dy, want_bias=True, f16x3=False):
     with torch.cuda.device(dev), _timed("linear_wgrad"):
         if f16x3:
             st = lib().vcnf_linear_wgrad_f16x3_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), b, int(n_in),
-                                                   int(n_out), 0, _ptr(saturation_counter(dev)), _stream())
+                                                   int(n_out), 0, int(bool(relu_x)), _ptr(saturation_counter(dev)), _stream())
         else:
             st = lib().vcnf_linear_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), b, int(n_in),
                                              int(n_out), 0, _stream())

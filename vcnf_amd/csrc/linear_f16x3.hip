@@ -32,6 +32,7 @@ struct ShLinearArgs {
   long long B;
   int K, N;
   long long ldn, ldk;
+  int relu_in, relu_out;   // ReLU on x while it is staged / on y before it is stored (nets/resnet.py:42, :46)
   int32_t* sat;
 };
 
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(const ShLinearArgs
 #pragma unroll
       for (int e = 0; e < 8; ++e) satm = fmaxf(satm, v8[e] == v8[e] ? 0.f : __builtin_inff());   // NaN inputs count
       half8 h8, l8;
-      split8<false>(v8, h8, l8, satm);
+      if (a.relu_in) split8<true>(v8, h8, l8, satm);
+      else split8<false>(v8, h8, l8, satm);
       const int at = ((j >> 1) * NCB + (r >> 5)) * 64 + (r & 31) + 32 * (j & 1);
       fhi[at] = __builtin_bit_cast(uint4, h8);
       flo[at] = __builtin_bit_cast(uint4, l8);
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(const ShLinearArgs
               const int r = 4 * j + q;
               v[q] = LOLO ? fmaf(fmaf(corr2[cb][r], kLoUnscale, corr[cb][r]), kLoUnscale, mainv[cb][r])
                           : fmaf(corr[cb][r], kLoUnscale, mainv[cb][r]);
+              if (a.relu_out) v[q] = fmaxf(v[q], 0.f);
             }
             *reinterpret_cast<floatx4*>(mystrip + c32 * 36 + 8 * j + 4 * kg) = v;
           }
@@ -181,13 +184,15 @@ extern "C" int vcnf_linear_f16x3_supported(int32_t k, int32_t n) {
 }
 
 extern "C" int vcnf_linear_f16x3_f32(const float* x, const float* w, const float* bias, float* y, int64_t batch,
-                                     int32_t k, int32_t n, int64_t ldn, int64_t ldk, int32_t* sat_count, void* stream) {
+                                     int32_t k, int32_t n, int64_t ldn, int64_t ldk, int relu_input, int relu_output,
+                                     int32_t* sat_count, void* stream) {
   if (!x || !w || !y) return VCNF_ERR_NULL;
   if (batch < 0) return VCNF_ERR_SHAPE;
   if (!vcnf_linear_f16x3_supported(k, n)) return VCNF_ERR_UNSUPPORTED;
   if (batch == 0) return VCNF_OK;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return VCNF_ERR_ALIGN;
-  ShLinearArgs a{x, w, bias, y, (long long)batch, k, n, (long long)ldn, (long long)ldk, sat_count};
+  ShLinearArgs a{x, w, bias, y, (long long)batch, k, n, (long long)ldn, (long long)ldk, relu_input ? 1 : 0,
+                 relu_output ? 1 : 0, sat_count};
   const size_t lds = (size_t)2 * (kShChunk / 16) * (kShTile / 32) * 64 * 16 + 4 * 32 * 36 * 4;
   dim3 grid((unsigned)((batch + kShTile - 1) / kShTile));
   hipStream_t st = (hipStream_t)stream;

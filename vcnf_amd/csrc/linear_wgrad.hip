@@ -28,6 +28,7 @@ struct WgradArgs {
   long long B, chunk; // samples per slice (multiple of 16)
   int IN, OUT, S, row_tiles;
   int col_tiles;      // split-half form: workgroups per row tile (64 input columns each)
+  int relu_x;         // split-half form: the layer's input is relu(x) (x = the residual stream, nets/resnet.py:42)
   int32_t* sat;       // split-half form: tiles that clamped a value at +-65504 (or NULL)
 };
 
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(kWgBlock, 2) void linear_wgrad_f16x3_kernel(const W
       _Pragma("unroll") for (int i = 0; i < 8; ++i)                                       \
         satm = fmaxf(satm, xv[BUF][u][kb][i] == xv[BUF][u][kb][i] ? 0.f : __builtin_inff()); \
       half8 bh, bl;                                                                       \
-      split8<false>(xv[BUF][u][kb], bh, bl, satm);                                        \
+      if (a.relu_x) split8<true>(xv[BUF][u][kb], bh, bl, satm);                           \
+      else split8<false>(xv[BUF][u][kb], bh, bl, satm);                                   \
       mainv[kb] = mfma32h(ah, bh, mainv[kb]);                                             \
       corr[kb] = mfma32h(ah, bl, corr[kb]);                                               \
       corr[kb] = mfma32h(al, bh, corr[kb]);                                               \
@@ -267,23 +269,25 @@ extern "C" int64_t vcnf_linear_wgrad_slices(int64_t batch, int32_t in_features, 
 }
 
 static int wgrad_run(const float* x, const float* dy, float* dw, float* db, float* workspace, int64_t workspace_floats,
-                     int64_t batch, int32_t in_features, int32_t out_features, int accumulate, bool f16x3,
+                     int64_t batch, int32_t in_features, int32_t out_features, int accumulate, int f16x3,
                      int32_t* sat_count, void* stream);
 
 extern "C" int vcnf_linear_wgrad_f32(const float* x, const float* dy, float* dw, float* db, float* workspace,
                                      int64_t workspace_floats, int64_t batch, int32_t in_features,
                                      int32_t out_features, int accumulate, void* stream) {
-  return wgrad_run(x, dy, dw, db, workspace, workspace_floats, batch, in_features, out_features, accumulate, false, nullptr, stream);
+  return wgrad_run(x, dy, dw, db, workspace, workspace_floats, batch, in_features, out_features, accumulate, 0, nullptr, stream);
 }
 
 extern "C" int vcnf_linear_wgrad_f16x3_f32(const float* x, const float* dy, float* dw, float* db, float* workspace,
                                            int64_t workspace_floats, int64_t batch, int32_t in_features,
-                                           int32_t out_features, int accumulate, int32_t* sat_count, void* stream) {
-  return wgrad_run(x, dy, dw, db, workspace, workspace_floats, batch, in_features, out_features, accumulate, true, sat_count, stream);
+                                           int32_t out_features, int accumulate, int relu_input,
+                                           int32_t* sat_count, void* stream) {
+  return wgrad_run(x, dy, dw, db, workspace, workspace_floats, batch, in_features, out_features, accumulate,
+                   relu_input ? 2 : 1, sat_count, stream);
 }
 
 static int wgrad_run(const float* x, const float* dy, float* dw, float* db, float* workspace, int64_t workspace_floats,
-                     int64_t batch, int32_t in_features, int32_t out_features, int accumulate, bool f16x3,
+                     int64_t batch, int32_t in_features, int32_t out_features, int accumulate, int f16x3,
                      int32_t* sat_count, void* stream) {
   if (!vcnf_linear_wgrad_supported(in_features, out_features)) return VCNF_ERR_UNSUPPORTED;
   if (batch < 1) return VCNF_ERR_SHAPE;
@@ -294,6 +298,7 @@ static int wgrad_run(const float* x, const float* dy, float* dw, float* db, floa
   WgradArgs a;
   a.sat = sat_count;
   a.col_tiles = 1;
+  a.relu_x = f16x3 == 2 ? 1 : 0;              // f16x3: 0 exact fp32 kernel, 1 split-half, 2 split-half on relu(x)
   a.x = x; a.dy = dy; a.part_w = workspace;
   a.part_b = db ? workspace + S * (long long)out_features * in_features : nullptr;
   a.B = batch; a.IN = in_features; a.OUT = out_features; a.S = (int)S;
@@ -301,7 +306,10 @@ static int wgrad_run(const float* x, const float* dy, float* dw, float* db, floa
   a.chunk = ((batch + S - 1) / S + 15) / 16 * 16;
   hipStream_t st = (hipStream_t)stream;
   // (the split-half kernel addresses its operands through 32-bit buffer descriptors)
-  if ((long long)batch * out_features * 4 >= (1ll << 31) || (long long)batch * in_features * 4 >= (1ll << 31)) f16x3 = false;
+  if (f16x3 && ((long long)batch * out_features * 4 >= (1ll << 31) || (long long)batch * in_features * 4 >= (1ll << 31))) {
+    if (f16x3 == 2) return VCNF_ERR_UNSUPPORTED;     // (the exact-fp32 kernel has no ReLU on load: the caller materialises relu(x))
+    f16x3 = 0;
+  }
   if (f16x3) {
     a.col_tiles = (in_features + 63) / 64;
     const dim3 grid((unsigned)(a.col_tiles * a.row_tiles * a.S));
