@@ -419,12 +419,14 @@ int vcnf_masked_affine_stack_bwd_f64(const double* z_out, const double* g_out, c
  * registers; arithmetic as VCNF_PREC_F16X3 of vcnf_rqs_layer_fused_f32 (lo*lo kept for k <= 48).  k % 16 == 0,
  * n % 4 == 0, and n <= 128 when k > 128.  x, y 16-byte aligned.  relu_input / relu_output: ReLU applied to x while it
  * is read / to y before it is stored (the residual block's activations, nets/resnet.py:42, :46, without their own
- * passes over memory).  Values beyond +-65504 (or NaN inputs) are clamped and counted in sat_count (device int32, may
- * be NULL) once per 64-sample tile. */
+ * passes over memory); mask / addend [batch, n] (16-byte aligned, may be NULL): y = addend + y * (mask > 0) - a ReLU's
+ * backward pass and the skip connection's gradient applied to an input gradient as it is stored (autograd of
+ * nets/resnet.py:42-57).  Values beyond +-65504 (or NaN inputs) are clamped and counted in sat_count (device int32,
+ * may be NULL) once per 64-sample tile. */
 int vcnf_linear_f16x3_supported(int32_t k, int32_t n);
 int vcnf_linear_f16x3_f32(const float* x, const float* w, const float* bias, float* y, int64_t batch,
                           int32_t k, int32_t n, int64_t ldn, int64_t ldk, int relu_input, int relu_output,
-                          int32_t* sat_count, void* stream);
+                          const float* mask, const float* addend, int32_t* sat_count, void* stream);
 
 /* A run of n_layers (<= vcnf_rqs_stack_fused_max_layers() = 16) RQS coupling layers of ONE shape and one spline
  * configuration in a single launch: the body of NormalizingFlow.log_prob / sample over consecutive

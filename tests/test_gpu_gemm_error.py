@@ -209,6 +209,11 @@ def test_training_linear_f16x3_error_not_above_library_fp32(hip, k, n):
     xr = torch.randn(200, k, generator=gen).cuda()
     assert torch.equal(_lib.linear_f16x3(xr, w, b, relu_in=True), _lib.linear_f16x3(torch.relu(xr), w, b))
     assert torch.equal(_lib.linear_f16x3(xr, w, b, relu_out=True), torch.relu(_lib.linear_f16x3(xr, w, b)))
+    if _lib.lib().vcnf_linear_f16x3_supported(n, k):
+        # ... and on an input gradient: result * (mask > 0) + addend as it is stored
+        gr, mk, ad = (torch.randn(200, m, generator=gen).cuda() for m in (n, k, k))
+        want = _lib.linear_f16x3(gr, w, None, input_grad=True) * (mk > 0) + ad
+        assert torch.equal(_lib.linear_f16x3(gr, w, None, input_grad=True, mask=mk, addend=ad), want)
     nf.check_saturation()
     # a value beyond the fp16 range is clamped and counted, never silently
     x = torch.randn(64, k, generator=gen).cuda()

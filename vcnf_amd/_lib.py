@@ -105,7 +105,7 @@ PROTOTYPES = {
     "vcnf_masked_affine_stack_bwd_f32": ([_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _INT, _P], _INT),
     "vcnf_masked_affine_stack_bwd_f64": ([_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _INT, _P], _INT),
     "vcnf_linear_f16x3_supported": ([_I32, _I32], _INT),
-    "vcnf_linear_f16x3_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I64, _I64, _INT, _INT, _P, _P], _INT),
+    "vcnf_linear_f16x3_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _I64, _I64, _INT, _INT, _P, _P, _P, _P], _INT),
     "vcnf_rqs_stack_fused_max_layers": ([], _I32),
     "vcnf_rqs_stack_fused_f32": ([_P, _P, _P, _P, _I64, ctypes.POINTER(RqsStackLayer), _I32, _I32, _I32, _I32, _I32, _I32,
                                   _I32, _I64, ctypes.POINTER(RqsCfg), _INT, _INT, _F32, _P, _P, _P, _P], _INT),
@@ -921,11 +921,13 @@ def masked_affine_stack_bwd(z_out, g_out, g_ld, table, goff, n_layers, n_grad, i
     return g_in, grads
 
 
-def linear_f16x3(x, weight, bias=None, input_grad=False, relu_in=False, relu_out=False):
+def linear_f16x3(x, weight, bias=None, input_grad=False, relu_in=False, relu_out=False, mask=None, addend=None):
     """nn.Linear on the fp16 split-half matrix path at training batch sizes (csrc/linear_f16x3.hip): ``x @ weight.T +
     bias`` for weight [out, in], or with ``input_grad`` the layer's input gradient ``x @ weight`` (x = the upstream
     gradient [B, out]).  The weight is read in place (no packed copy); ``relu_in`` / ``relu_out`` apply ReLU to x as it is
-    read / to the result before it is stored.  Clamped values are counted in saturation_counter (nf.check_saturation())."""
+    read / to the result before it is stored; ``mask`` / ``addend`` [B, n]: result = addend + result * (mask > 0) (a ReLU's
+    backward and a skip connection's gradient on the way out).  Clamped values are counted in saturation_counter
+    (nf.check_saturation())."""
     dev = require_device(x, weight, bias, allow_grad=True)
     x, weight = x.detach().contiguous(), weight.detach().contiguous()
     b, k = x.shape
@@ -937,10 +939,14 @@ def linear_f16x3(x, weight, bias=None, input_grad=False, relu_in=False, relu_out
         n, ldn, ldk = n_out, n_in, 1
         assert k == n_in
     y = torch.empty(b, n, dtype=torch.float32, device=dev)
+    if mask is not None:
+        mask = mask.detach().contiguous()
+    if addend is not None:
+        addend = addend.detach().contiguous()
     with torch.cuda.device(dev), _timed("linear_f16x3"):
         st = lib().vcnf_linear_f16x3_f32(_ptr(x), _ptr(weight), _ptr(bias.detach().contiguous() if bias is not None else None),
                                          _ptr(y), b, int(k), int(n), int(ldn), int(ldk), int(bool(relu_in)), int(bool(relu_out)),
-                                         _ptr(saturation_counter(dev)), _stream())
+                                         _ptr(mask), _ptr(addend), _ptr(saturation_counter(dev)), _stream())
     _check(st, "vcnf_linear_f16x3_f32")
     return y
 

@@ -396,12 +396,21 @@ class ResBlockFn(torch.autograd.Function):
             g_c, g_gate = g.contiguous(), None
         need = ctx.needs_input_grad
         gw1, gb1 = _wgrad_or_torch(t1, g_c) if (need[4] or need[5]) else (None, None)
-        g_a = _lib.resblock_op(2, _dgrad(g_c, w1), t1)
+        sq1 = w1.shape[0] == w1.shape[1] and _f16x3_ok(g_c, w1.shape[0], w1.shape[1])
+        # square layers: the ReLU's backward (and, below, the skip connection's gradient) applied as the split-half kernel
+        # stores the input gradient - no elementwise pass of their own
+        g_a = _lib.linear_f16x3(g_c, w1, None, input_grad=True, mask=t1) if sq1 else _lib.resblock_op(2, _dgrad(g_c, w1), t1)
         if ctx.fused_relu:          # t0 is the block input h: relu on load
             gw0, gb0 = _lib.linear_wgrad(t0, g_a, f16x3=TRAIN_MATRIX_PATH == 'fp16x3', relu_x=True) if (need[2] or need[3]) else (None, None)
         else:
             gw0, gb0 = _wgrad_or_torch(t0, g_a) if (need[2] or need[3]) else (None, None)
-        g_h = _lib.resblock_op(3, _dgrad(g_a, w0), t0, g) if need[0] else None
+        sq0 = w0.shape[0] == w0.shape[1] and _f16x3_ok(g_a, w0.shape[0], w0.shape[1])
+        if not need[0]:
+            g_h = None
+        elif sq0:
+            g_h = _lib.linear_f16x3(g_a, w0, None, input_grad=True, mask=t0, addend=g)
+        else:
+            g_h = _lib.resblock_op(3, _dgrad(g_a, w0), t0, g)
         return g_h, (g_gate if ctx.gated and need[1] else None), gw0, gb0, gw1, gb1
 
 

@@ -33,6 +33,8 @@ struct ShLinearArgs {
   int K, N;
   long long ldn, ldk;
   int relu_in, relu_out;   // ReLU on x while it is staged / on y before it is stored (nets/resnet.py:42, :46)
+  const float* mask;       // [B, N] or NULL: y *= (mask > 0)   - the ReLU's backward on an input gradient
+  const float* addend;     // [B, N] or NULL: y += addend        - the skip connection's gradient (after the mask)
   int32_t* sat;
 };
 
@@ -156,11 +158,24 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(const ShLinearArgs
             if (row < rows) {
               float* dst = a.y + (b0 + row) * N + col;
               if (col + 3 < N) {
-                *reinterpret_cast<floatx4*>(dst) = v;
+                floatx4 o = v;
+                if (a.mask) {
+                  const floatx4 m = *reinterpret_cast<const floatx4*>(a.mask + (b0 + row) * N + col);
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) o[q] = m[q] > 0.f ? o[q] : 0.f;
+                }
+                if (a.addend) o += *reinterpret_cast<const floatx4*>(a.addend + (b0 + row) * N + col);
+                *reinterpret_cast<floatx4*>(dst) = o;
               } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                  if (col + q < N) dst[q] = v[q];
+                for (int q = 0; q < 4; ++q) {
+                  if (col + q < N) {
+                    float o = v[q];
+                    if (a.mask) o = a.mask[(b0 + row) * N + col + q] > 0.f ? o : 0.f;
+                    if (a.addend) o += a.addend[(b0 + row) * N + col + q];
+                    dst[q] = o;
+                  }
+                }
               }
             }
           }
@@ -185,14 +200,15 @@ extern "C" int vcnf_linear_f16x3_supported(int32_t k, int32_t n) {
 
 extern "C" int vcnf_linear_f16x3_f32(const float* x, const float* w, const float* bias, float* y, int64_t batch,
                                      int32_t k, int32_t n, int64_t ldn, int64_t ldk, int relu_input, int relu_output,
-                                     int32_t* sat_count, void* stream) {
+                                     const float* mask, const float* addend, int32_t* sat_count, void* stream) {
   if (!x || !w || !y) return VCNF_ERR_NULL;
   if (batch < 0) return VCNF_ERR_SHAPE;
   if (!vcnf_linear_f16x3_supported(k, n)) return VCNF_ERR_UNSUPPORTED;
   if (batch == 0) return VCNF_OK;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return VCNF_ERR_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(addend)) & 15) return VCNF_ERR_ALIGN;
   ShLinearArgs a{x, w, bias, y, (long long)batch, k, n, (long long)ldn, (long long)ldk, relu_input ? 1 : 0,
-                 relu_output ? 1 : 0, sat_count};
+                 relu_output ? 1 : 0, mask, addend, sat_count};
   const size_t lds = (size_t)2 * (kShChunk / 16) * (kShTile / 32) * 64 * 16 + 4 * 32 * 36 * 4;
   dim3 grid((unsigned)((batch + kShTile - 1) / kShTile));
   hipStream_t st = (hipStream_t)stream;
