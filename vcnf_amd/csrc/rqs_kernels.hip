@@ -84,10 +84,21 @@ __global__ __launch_bounds__(kBlock) void rqs_coupling_kernel(const CouplingArgs
   if (a.sh_mode == 1) {
     RqsConst cs = c;
     cs.K = K;
-    for (int f = tid; f < a.d_id; f += kBlock) {
-      SplitLogits p{a.sh_w + (long long)f * K, a.sh_h + (long long)f * K, a.sh_d + (long long)f * a.Pd,
-                    K, 1.f, c.edge_logit, c.tails};
-      rqs_build_table(p, cs, tab + f * tabw);
+    if constexpr (KT > 0) {
+      // one thread per (feature, table column), the column's logits requested before the first is used (one memory
+      // latency per workgroup instead of one per loop iteration; bitwise the same table, rqs_math.hpp)
+      for (int i = tid; i < 3 * a.d_id; i += kBlock) {
+        const int f = i % a.d_id;
+        SplitLogits p{a.sh_w + (long long)f * K, a.sh_h + (long long)f * K, a.sh_d + (long long)f * a.Pd,
+                      K, 1.f, c.edge_logit, c.tails};
+        rqs_build_table_part_k<(KT > 0 ? KT : 4)>(p, cs, tab + f * tabw, 1, i / a.d_id);
+      }
+    } else {
+      for (int f = tid; f < a.d_id; f += kBlock) {
+        SplitLogits p{a.sh_w + (long long)f * K, a.sh_h + (long long)f * K, a.sh_d + (long long)f * a.Pd,
+                      K, 1.f, c.edge_logit, c.tails};
+        rqs_build_table(p, cs, tab + f * tabw);
+      }
     }
   }
 
@@ -204,10 +215,21 @@ __global__ __launch_bounds__(kBlock) void rqs_coupling_pf_kernel(const CouplingA
   if (a.sh_mode == 1) {
     RqsConst cs = c;
     cs.K = K;
-    for (int f = tid; f < a.d_id; f += kBlock) {
-      SplitLogits p{a.sh_w + (long long)f * K, a.sh_h + (long long)f * K, a.sh_d + (long long)f * a.Pd,
-                    K, 1.f, c.edge_logit, c.tails};
-      rqs_build_table(p, cs, tab + f * tabw);
+    if constexpr (KT > 0) {
+      // one thread per (feature, table column), the column's logits requested before the first is used (one memory
+      // latency per workgroup instead of one per loop iteration; bitwise the same table, rqs_math.hpp)
+      for (int i = tid; i < 3 * a.d_id; i += kBlock) {
+        const int f = i % a.d_id;
+        SplitLogits p{a.sh_w + (long long)f * K, a.sh_h + (long long)f * K, a.sh_d + (long long)f * a.Pd,
+                      K, 1.f, c.edge_logit, c.tails};
+        rqs_build_table_part_k<(KT > 0 ? KT : 4)>(p, cs, tab + f * tabw, 1, i / a.d_id);
+      }
+    } else {
+      for (int f = tid; f < a.d_id; f += kBlock) {
+        SplitLogits p{a.sh_w + (long long)f * K, a.sh_h + (long long)f * K, a.sh_d + (long long)f * a.Pd,
+                      K, 1.f, c.edge_logit, c.tails};
+        rqs_build_table(p, cs, tab + f * tabw);
+      }
     }
   }
 
@@ -505,10 +527,10 @@ struct IdHalfArgs {
   int32_t* bad;
   long long B;
   int D, d_id, chunks, nd, apply, cond_out;
+  int rows_wg;         // rows per workgroup (a multiple of 16)
   RqsConst c;
 };
 
-constexpr int kIdRows = 128;     // rows per workgroup (32 per wave)
 
 template <int K, bool INV>
 __global__ __launch_bounds__(kBlock) void rqs_identity_half_kernel(const IdHalfArgs a) {
@@ -525,7 +547,8 @@ __global__ __launch_bounds__(kBlock) void rqs_identity_half_kernel(const IdHalfA
     if (wave < 3 && fok) {                       // wave 0: x knots, 1: y knots, 2: derivatives
       SplitLogits p{a.sw + (long long)f * K, a.sh + (long long)f * K, a.sd + (long long)f * a.nd,
                     K, c.wh_scale, c.edge_logit, c.tails};
-      rqs_build_table_part(p, c, tabT + lane, 64, wave);
+      rqs_build_table_part_k<K>(p, c, tabT + lane, 64, wave);      // logits requested first: one memory latency (the
+                                                                    // run-time loops waited for a load per iteration)
     }
     __syncthreads();
   }
@@ -533,10 +556,10 @@ __global__ __launch_bounds__(kBlock) void rqs_identity_half_kernel(const IdHalfA
   const float* t = tabT + lane;
   const float* key = t + (INV ? (K + 1) * 64 : 0);
   bool bad = false;
-  const long long r0 = rb * kIdRows + wave * (kIdRows / 4);
+  const long long r0 = rb * a.rows_wg + wave * (a.rows_wg / 4);
   constexpr int U = 4;
 #pragma unroll 1
-  for (int i = 0; i < kIdRows / 4; i += U) {
+  for (int i = 0; i < a.rows_wg / 4; i += U) {
     float v[U], yv[U], lad[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -873,7 +896,9 @@ extern "C" int vcnf_rqs_identity_half_f32(const float* x, float* y, float* cond_
   a.B = batch; a.D = features; a.d_id = d_id; a.chunks = (d_id + 63) / 64;
   a.apply = any_sh ? 1 : 0;
   a.cond_out = cond_sees_output ? 1 : 0;
-  const long long rblocks = (batch + kIdRows - 1) / kIdRows;
+  a.rows_wg = 128;      // (512 rows per workgroup for large batches - fewer table builds - measured slower: 1.59 vs 1.47 ms at
+                        // 524 288 x 512, the kernel is bound by its strided row accesses, not by the set-up)
+  const long long rblocks = (batch + a.rows_wg - 1) / a.rows_wg;
   if (rblocks * a.chunks > 0x7fffffffLL) return VCNF_ERR_SHAPE;
   dim3 grid((unsigned)(rblocks * a.chunks));
   hipStream_t st = (hipStream_t)stream;
