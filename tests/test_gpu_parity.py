@@ -1108,6 +1108,32 @@ def test_masked_affine_stack_single_launch_matches_per_layer(hip, d, h, nets, le
     assert torch.allclose(res[0][ok], res[1][ok], **tol)
 
 
+def test_graphed_flow_over_masked_affine_stack_and_actnorm(hip):
+    """The reference drivers' model family under nf.GraphedFlow: log_prob / sample_from captured into a HIP graph (the
+    whole run is one kernel node; ActNorm's initialised-flag is read on the host once, so the capture does not hit the
+    per-call device test of normalization.py:29 / :40) replay the eager results bit for bit in fp64, also after an
+    in-place parameter update (the kernel reads the parameters in place)."""
+    torch.manual_seed(12)
+    model = _realnvp_like_reference_drivers(2, 16, 8, torch.float64)
+    B = 1024
+    x0 = torch.randn(B, 2, device="cuda", dtype=torch.float64)
+    with torch.no_grad():
+        model.log_prob(x0)                                   # data-dependent ActNorm initialisation (eager, first batch)
+    g = nf.GraphedFlow(model, batch=B)
+    for trial in range(3):
+        x, eps = torch.randn(B, 2, device="cuda", dtype=torch.float64), torch.randn(B, 2, device="cuda", dtype=torch.float64)
+        if trial == 2:
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(0.01 * torch.randn_like(p))
+        with torch.no_grad():
+            want_lp = model.log_prob(x)
+            want_z, want_lq = model.sample_from(eps)
+        lp = g.log_prob(x).clone()
+        z, lq = g.sample_from(eps)
+        assert torch.equal(lp, want_lp) and torch.equal(z, want_z) and torch.equal(lq, want_lq), trial
+
+
 def test_data_mutation_needs_refresh_packed(hip):
     """the packed weight caches key on (data_ptr, _version); ``p.data`` edits do not bump _version.
     refresh_packed() (also run by train() / eval() / load_state_dict()) makes the fused kernel see them."""

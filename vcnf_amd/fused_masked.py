@@ -105,7 +105,10 @@ def plan(order, start, z):
 
 
 def _stamp(flow):
-    return (id(getattr(flow, 's', None)), id(getattr(flow, 't', None)), flow.__dict__.get('_init_done_host', None))
+    # ActNorm: whether it has seen its first batch decides whether it can be part of a run (asked of the layer itself: the
+    # answer is cached on the host once it is yes, so this synchronises only while the layer is still uninitialised)
+    init = flow._initialised() if hasattr(flow, '_initialised') else None
+    return (id(getattr(flow, 's', None)), id(getattr(flow, 't', None)), init)
 
 
 def cached_plan(owner, order, start, z):
