@@ -536,6 +536,18 @@ int vcnf_affine_const_f32(const float* z, const float* s, const float* t, float*
 int vcnf_permute_f32(const float* z, const int32_t* idx, float* out,
                      int64_t batch, int32_t channels, int32_t inner, void* stream);
 
+/* The channel partition of a coupling as two tensors, and back (training path: the gather
+ * inputs[:, identity_features] / inputs[:, transform_features] and the scatter outputs[:, ...] = ... of
+ * flows/neural_spline/coupling.py:86-88, :122-124 - each the other's VJP).  z / out [B, C] row-major;
+ * first_part [B, first], second_part [B, C - first].
+ * split:  first_part[b, c] = z[b, idx[c]] (c < first), second_part[b, c - first] = z[b, idx[c]] (c >= first).
+ * merge:  out[b, c] = p < first ? first_part[b, p] : second_part[b, p - first] with p = idx[c]
+ *         (idx of merge = the inverse permutation of the idx of split). */
+int vcnf_split_columns_f32(const float* z, const int32_t* idx, float* first_part, float* second_part,
+                           int64_t batch, int32_t channels, int32_t first, void* stream);
+int vcnf_merge_columns_f32(const float* first_part, const float* second_part, const int32_t* idx, float* out,
+                           int64_t batch, int32_t channels, int32_t first, void* stream);
+
 /* DiagGaussian.log_prob (normflow/distributions/base.py:644-652).
  * loc, log_scale [D]; log_temperature = log(T) or 0; logp[B] per ld_mode. */
 int vcnf_diag_gaussian_log_prob_f32(const float* z, const float* loc, const float* log_scale,
@@ -573,6 +585,10 @@ int vcnf_affine_const_f64(const double* z, const double* s, const double* t, dou
                           int64_t batch, int32_t channels, int32_t inner, int inverse, void* stream);
 int vcnf_permute_f64(const double* z, const int32_t* idx, double* out,
                      int64_t batch, int32_t channels, int32_t inner, void* stream);
+int vcnf_split_columns_f64(const double* z, const int32_t* idx, double* first_part, double* second_part,
+                           int64_t batch, int32_t channels, int32_t first, void* stream);
+int vcnf_merge_columns_f64(const double* first_part, const double* second_part, const int32_t* idx, double* out,
+                           int64_t batch, int32_t channels, int32_t first, void* stream);
 int vcnf_diag_gaussian_log_prob_f64(const double* z, const double* loc, const double* log_scale,
                                     double log_temperature, double* logp, int64_t batch,
                                     int32_t features, int ld_mode, double ld_sign, void* stream);

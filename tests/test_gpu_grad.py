@@ -476,6 +476,37 @@ def test_image_rqs_coupling_gradients(hip):
         _grad_compare(getattr(m, dirn), lambda s, x, c: getattr(oracle_image_rqs_coupling(s), ofn)(x, c), sd,
                       [T(fx["x"]), T(fx["ctx"])], "image rqs " + dirn, loss_of=pick)
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["fp32", "fp64"])
+@pytest.mark.parametrize("c,first,b", [(64, 32, 4099), (7, 3, 1000), (5, 0, 17), (4, 4, 33), (1, 1, 3)])
+def test_split_and_merge_columns_are_the_channel_partition_and_its_vjp(hip, c, first, b, dtype):
+    """coupling.py:86-88 / :122-124 as one pass each way: exact copies, and each direction is the other's VJP."""
+    g = torch.Generator().manual_seed(c * 131 + first)
+    perm = torch.randperm(c, generator=g)
+    gather = perm.to(torch.int32).cuda()
+    scatter = torch.argsort(perm).to(torch.int32).cuda()
+    z = torch.randn(b, c, generator=g, dtype=dtype).cuda().requires_grad_(True)
+    pa, pb = vag.SplitColumnsFn.apply(z, gather, scatter, first)
+    ref = z.detach()[:, perm.cuda()]
+    assert torch.equal(pa.detach(), ref[:, :first]) and torch.equal(pb.detach(), ref[:, first:])
+    assert pa.is_contiguous() and pb.is_contiguous()
+    out = vag.MergeColumnsFn.apply(pa * 2.0, pb * 3.0, gather, scatter)
+    want = torch.cat([ref[:, :first] * 2.0, ref[:, first:] * 3.0], 1)[:, torch.argsort(perm).cuda()]
+    assert torch.equal(out.detach(), want)
+    w = torch.randn(b, c, generator=g, dtype=dtype).cuda()
+    (out * w).sum().backward()
+    scale = torch.empty(c, dtype=dtype)
+    scale[perm[:first]] = 2.0
+    scale[perm[first:]] = 3.0
+    assert torch.equal(z.grad, w * scale.cuda())
+    # one of the two parts unused downstream: its gradient arrives as zeros
+    z2 = z.detach().clone().requires_grad_(True)
+    qa, qb = vag.SplitColumnsFn.apply(z2, gather, scatter, first)
+    (qb.sum() if first < c else qa.sum()).backward()
+    expect = torch.zeros(c, dtype=dtype)
+    expect[perm[first:] if first < c else perm[:first]] = 1.0
+    assert torch.equal(z2.grad, expect.cuda().expand(b, c))
+
+
 @pytest.mark.parametrize("n_in,n_out,b", [(128, 128, 16384 + 37), (48, 128, 8192), (16, 128, 9000), (128, 736, 10000), (64, 5, 300)])
 def test_linear_wgrad_kernel(hip, n_in, n_out, b):
     """csrc/linear_wgrad.hip: dW = dy^T x and db = sum dy with the batch reduction split over the chip, against fp64

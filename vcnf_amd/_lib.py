@@ -128,6 +128,8 @@ PROTOTYPES = {
     "vcnf_masked_affine_f32": ([_P, _P, _P, _P, _P, _P, _I64, _I32, _INT, _INT, _F32, _P], _INT),
     "vcnf_affine_const_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _INT, _P], _INT),
     "vcnf_permute_f32": ([_P, _P, _P, _I64, _I32, _I32, _P], _INT),
+    "vcnf_split_columns_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _P], _INT),
+    "vcnf_merge_columns_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _P], _INT),
     "vcnf_diag_gaussian_log_prob_f32": ([_P, _P, _P, _F32, _P, _I64, _I32, _INT, _F32, _P], _INT),
     "vcnf_diag_gaussian_sample_f32": ([_P, _P, _P, _F32, _P, _P, _I64, _I32, _P], _INT),
     "vcnf_linear_probe_f32": ([_P, _P, _P, _P, _I64, _I32, _I32, _INT, _INT, _P, _P], _INT),
@@ -137,6 +139,8 @@ PROTOTYPES = {
     "vcnf_masked_affine_f64": ([_P, _P, _P, _P, _P, _P, _I64, _I32, _INT, _INT, _F64, _P], _INT),
     "vcnf_affine_const_f64": ([_P, _P, _P, _P, _I64, _I32, _I32, _INT, _P], _INT),
     "vcnf_permute_f64": ([_P, _P, _P, _I64, _I32, _I32, _P], _INT),
+    "vcnf_split_columns_f64": ([_P, _P, _P, _P, _I64, _I32, _I32, _P], _INT),
+    "vcnf_merge_columns_f64": ([_P, _P, _P, _P, _I64, _I32, _I32, _P], _INT),
     "vcnf_diag_gaussian_log_prob_f64": ([_P, _P, _P, _F64, _P, _I64, _I32, _INT, _F64, _P], _INT),
     "vcnf_diag_gaussian_sample_f64": ([_P, _P, _P, _F64, _P, _P, _I64, _I32, _P], _INT),
 }
@@ -1065,6 +1069,38 @@ def permute(z, idx32):
     with torch.cuda.device(dev):
         st = getattr(lib(), "vcnf_permute" + _sfx(z))(_ptr(z), _ptr(idx32), _ptr(out), b, c, inner, _stream())
     _check(st, "vcnf_permute" + _sfx(z))
+    return out
+
+
+def split_columns(z, idx32, first):
+    """(z[:, idx[:first]], z[:, idx[first:]]) of z [B, C] as two contiguous tensors, one pass."""
+    dev = require_device(z, f64=True)
+    z = z.contiguous()
+    b, c = z.shape
+    if idx32.numel() != c or not 0 <= first <= c:
+        raise VcnfError("split_columns: index of %d entries / first part of %d columns for %d columns" % (idx32.numel(), first, c))
+    pa = torch.empty(b, first, dtype=z.dtype, device=dev)
+    pb = torch.empty(b, c - first, dtype=z.dtype, device=dev)
+    with torch.cuda.device(dev):
+        st = getattr(lib(), "vcnf_split_columns" + _sfx(z))(_ptr(z), _ptr(idx32), _ptr(pa), _ptr(pb), b, c, first, _stream())
+    _check(st, "vcnf_split_columns" + _sfx(z))
+    return pa, pb
+
+
+def merge_columns(pa, pb, idx32):
+    """cat([pa, pb], 1)[:, idx] for pa [B, Ca], pb [B, Cb] as one pass (no concatenated intermediate)."""
+    dev = require_device(pa, pb, f64=True)
+    if pa.dtype != pb.dtype or pa.shape[0] != pb.shape[0]:
+        raise VcnfError("merge_columns: parts of different dtype / batch")
+    pa, pb = pa.contiguous(), pb.contiguous()
+    b, first = pa.shape
+    c = first + pb.shape[1]
+    if idx32.numel() != c:
+        raise VcnfError("merge_columns: index of %d entries for %d columns" % (idx32.numel(), c))
+    out = torch.empty(b, c, dtype=pa.dtype, device=dev)
+    with torch.cuda.device(dev):
+        st = getattr(lib(), "vcnf_merge_columns" + _sfx(pa))(_ptr(pa), _ptr(pb), _ptr(idx32), _ptr(out), b, c, first, _stream())
+    _check(st, "vcnf_merge_columns" + _sfx(pa))
     return out
 
 

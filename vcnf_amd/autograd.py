@@ -242,6 +242,39 @@ class PermuteFn(torch.autograd.Function):
         return _lib.permute(g.contiguous(), ctx.back), None, None
 
 
+class SplitColumnsFn(torch.autograd.Function):
+    """(z[:, gather[:first]], z[:, gather[first:]]) as two contiguous tensors in one pass (vcnf_split_columns); the VJP
+    is MergeColumnsFn's forward.  Replaces a full column permutation, two slice copies and, in the backward pass, two
+    zero fills, two slice writes and an add."""
+
+    @staticmethod
+    def forward(ctx, z, gather32, scatter32, first):
+        ctx.scatter = scatter32
+        with torch.no_grad():
+            return _lib.split_columns(z, gather32, first)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, ga, gb):
+        return _lib.merge_columns(ga, gb, ctx.scatter), None, None, None
+
+
+class MergeColumnsFn(torch.autograd.Function):
+    """cat([a, b], 1)[:, scatter] in one pass (vcnf_merge_columns); the VJP is SplitColumnsFn's forward."""
+
+    @staticmethod
+    def forward(ctx, a, b, gather32, scatter32):
+        ctx.gather, ctx.first = gather32, a.shape[1]
+        with torch.no_grad():
+            return _lib.merge_columns(a, b, scatter32)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        ga, gb = _lib.split_columns(g, ctx.gather, ctx.first)
+        return ga, gb, None, None
+
+
 class DiagGaussianLogProbFn(torch.autograd.Function):
     """vcnf_diag_gaussian_log_prob_f32: lp = const - sum(ls + ((z - loc) / e^ls)^2 / 2)."""
 

@@ -228,6 +228,37 @@ __global__ __launch_bounds__(kBlock) void permute_kernel(const PermArgsT<T> a) {
   }
 }
 
+// The channel partition of a coupling as two tensors and back (the training path's gather / scatter,
+// flows/neural_spline/coupling.py:86-88 and :122-124): idx lists the columns of the first part, then those of the
+// second.  One pass each way - no [B, C] intermediate, no slice copies, and each direction is the other's VJP.
+template <typename T>
+struct SplitArgsT {
+  const T* z;          // split: source [B, C]; merge: unused
+  T* out;              // merge: destination [B, C]; split: unused
+  T* a;                // [B, na]
+  T* b;                // [B, C - na]
+  const int32_t* idx;  // split: column of z that gathered position c reads; merge: gathered position that column c reads
+  long long total;     // B * C
+  int C, na;
+};
+
+template <typename T, bool MERGE>
+__global__ __launch_bounds__(kBlock) void split_merge_kernel(const SplitArgsT<T> a) {
+  const int nb = a.C - a.na;
+  for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < a.total; e += (long long)gridDim.x * kBlock) {
+    const long long r = e / a.C;
+    const int c = (int)(e - r * a.C);
+    if (MERGE) {
+      const int p = a.idx[c];
+      a.out[e] = p < a.na ? a.a[r * a.na + p] : a.b[r * nb + (p - a.na)];
+    } else {
+      const T v = a.z[r * a.C + a.idx[c]];
+      if (c < a.na) a.a[r * a.na + c] = v;
+      else a.b[r * nb + (c - a.na)] = v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ diagonal Gaussian
 template <typename T>
 struct GaussArgsT {
@@ -451,6 +482,38 @@ extern "C" int vcnf_permute_f32(const float* z, const int32_t* idx, float* out,
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(permute_kernel<float>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
   return launched();
+}
+
+template <typename T, bool MERGE>
+static int split_merge(const T* z, T* out, T* pa, T* pb, const int32_t* idx, int64_t batch, int32_t channels,
+                       int32_t first, void* stream) {
+  if (batch < 0 || channels < 1 || first < 0 || first > channels) return VCNF_ERR_SHAPE;
+  if (batch == 0) return VCNF_OK;
+  if (!(MERGE ? (const void*)out : (const void*)z) || !idx || (first > 0 && !pa) || (first < channels && !pb)) return VCNF_ERR_NULL;
+  SplitArgsT<T> a{z, out, pa, pb, idx, batch * (long long)channels, channels, first};
+  long long blocks = (a.total + kBlock - 1) / kBlock;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL((split_merge_kernel<T, MERGE>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a);
+  return launched();
+}
+
+extern "C" int vcnf_split_columns_f32(const float* z, const int32_t* idx, float* first_part, float* second_part,
+                                      int64_t batch, int32_t channels, int32_t first, void* stream) {
+  return split_merge<float, false>(z, nullptr, first_part, second_part, idx, batch, channels, first, stream);
+}
+extern "C" int vcnf_merge_columns_f32(const float* first_part, const float* second_part, const int32_t* idx, float* out,
+                                      int64_t batch, int32_t channels, int32_t first, void* stream) {
+  return split_merge<float, true>(nullptr, out, const_cast<float*>(first_part), const_cast<float*>(second_part), idx,
+                                  batch, channels, first, stream);
+}
+extern "C" int vcnf_split_columns_f64(const double* z, const int32_t* idx, double* first_part, double* second_part,
+                                      int64_t batch, int32_t channels, int32_t first, void* stream) {
+  return split_merge<double, false>(z, nullptr, first_part, second_part, idx, batch, channels, first, stream);
+}
+extern "C" int vcnf_merge_columns_f64(const double* first_part, const double* second_part, const int32_t* idx, double* out,
+                                      int64_t batch, int32_t channels, int32_t first, void* stream) {
+  return split_merge<double, true>(nullptr, out, const_cast<double*>(first_part), const_cast<double*>(second_part), idx,
+                                   batch, channels, first, stream);
 }
 
 static int gauss(const float* in, const float* loc, const float* log_scale, float log_temperature,

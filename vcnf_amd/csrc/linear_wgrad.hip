@@ -215,32 +215,42 @@ struct WreduceArgs {
   const float* part;
   float* out;
   long long n;       // elements of one slice
+  const float* part2;   // second set of partial results reduced by the same launch (the bias gradient), or NULL
+  float* out2;
+  long long n2;
+  int blocks1;       // workgroups of the first set
   int S, accumulate;
 };
 
 // column sums of the [S, n] partial results: a workgroup owns 64 columns, its four waves take every fourth slice
-// (256-byte row segments, eight loads in flight), LDS adds the four in a fixed order
+// (256-byte row segments, eight loads in flight), LDS adds the four in a fixed order.  Weight and bias partials go
+// through one launch (the workgroups past blocks1 own the second set): the same sums in the same order as two
+// launches, one launch gap less per dense layer of the backward pass.
 __global__ __launch_bounds__(kWgBlock) void wgrad_reduce_kernel(const WreduceArgs a) {
   __shared__ float sm[4][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long long col = (long long)blockIdx.x * 64 + c;
+  const bool second = (int)blockIdx.x >= a.blocks1;
+  const float* part = second ? a.part2 : a.part;
+  float* out = second ? a.out2 : a.out;
+  const long long n = second ? a.n2 : a.n;
+  const long long col = (long long)(second ? blockIdx.x - a.blocks1 : blockIdx.x) * 64 + c;
   float t = 0.f;
-  if (col < a.n) {
+  if (col < n) {
     int s = g;
     for (; s + 28 < a.S; s += 32) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = a.part[(long long)(s + 4 * u) * a.n + col];
+      for (int u = 0; u < 8; ++u) v[u] = part[(long long)(s + 4 * u) * n + col];
 #pragma unroll
       for (int u = 0; u < 8; ++u) t += v[u];
     }
-    for (; s < a.S; s += 4) t += a.part[(long long)s * a.n + col];
+    for (; s < a.S; s += 4) t += part[(long long)s * n + col];
   }
   sm[g][c] = t;
   __syncthreads();
-  if (g == 0 && col < a.n) {
+  if (g == 0 && col < n) {
     const float r = ((sm[0][c] + sm[1][c]) + sm[2][c]) + sm[3][c];
-    a.out[col] = a.accumulate ? a.out[col] + r : r;
+    out[col] = a.accumulate ? out[col] + r : r;
   }
 }
 
@@ -329,10 +339,8 @@ static int wgrad_run(const float* x, const float* dy, float* dw, float* db, floa
   }
   WreduceArgs r;
   r.part = a.part_w; r.out = dw; r.n = (long long)out_features * in_features; r.S = (int)S; r.accumulate = accumulate ? 1 : 0;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((r.n + 63) / 64)), dim3(kWgBlock), 0, st, r);
-  if (db) {
-    r.part = a.part_b; r.out = db; r.n = out_features;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((r.n + 63) / 64)), dim3(kWgBlock), 0, st, r);
-  }
+  r.blocks1 = (int)((r.n + 63) / 64);
+  r.part2 = db ? a.part_b : nullptr; r.out2 = db; r.n2 = db ? out_features : 0;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(r.blocks1 + (r.n2 + 63) / 64)), dim3(kWgBlock), 0, st, r);
   return hipGetLastError() == hipSuccess ? VCNF_OK : VCNF_ERR_LAUNCH;
 }

@@ -264,13 +264,13 @@ class PiecewiseRationalQuadraticCoupling(Flow):
         return any(p.requires_grad for p in self.parameters())
 
     def _run_differentiable(self, inputs, context, sampling):
-        """Training path (coupling.py:70-125 as written there): gather / conditioner / scatter are
-        PyTorch ops; the two spline families and their gradients are HIP kernels that read the
-        conditioner output and the shared logits in place (vcnf_amd.autograd)."""
+        """Training path (coupling.py:70-125 as written there): the channel partition and its
+        inverse are one pass each (autograd.SplitColumnsFn / MergeColumnsFn, each the other's VJP),
+        the conditioner is PyTorch ops over the training GEMM kernels; the two spline families and
+        their gradients are HIP kernels that read the conditioner output and the shared logits in
+        place (vcnf_amd.autograd)."""
         gather, scatter = self._split_index(inputs.device)
-        parts = autograd.PermuteFn.apply(inputs, gather, scatter)
-        xi = parts[:, :self.num_identity_features].contiguous()
-        xt = parts[:, self.num_identity_features:].contiguous()
+        xi, xt = autograd.SplitColumnsFn.apply(inputs, gather, scatter, self.num_identity_features)
         lad = 0.0
         uncond = self.unconditional_transform
         if sampling and uncond is not None:
@@ -281,7 +281,7 @@ class PiecewiseRationalQuadraticCoupling(Flow):
         if (not sampling) and uncond is not None:
             xi, lad_i = uncond.forward(xi)
             lad = lad + lad_i
-        out = autograd.PermuteFn.apply(torch.cat([xi, yt], dim=1), scatter, gather)
+        out = autograd.MergeColumnsFn.apply(xi, yt, gather, scatter)
         return out, lad
 
     def _run_image(self, inputs, context, sampling):
