@@ -46,7 +46,12 @@ constexpr int kShChunk = 128;          // k values staged per pass (8 k-steps of
 // and the loads coalesce across lanes).  As eight 4-byte loads from 64 different lines the forward was bound by the
 // address path: 79 us for 131 072 x 128 x 128 against the library's 51.
 template <bool LOLO, bool WROWS>
-__global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(const ShLinearArgs a) {
+__global__ __launch_bounds__(256, (!LOLO && !WROWS) ? 3 : 2) void linear_f16x3_kernel(const ShLinearArgs a) {
+  // the input-gradient form requests the mask / addend values of a column block's four row groups together (below);
+  // the forward forms keep the plain epilogue and their register allocation (measured: with the batched epilogue and
+  // three workgroups per compute unit forced, 67 -> 74 us per forward launch of the C3 training step, 59 -> 54 us per
+  // input-gradient launch)
+  constexpr bool EPI = !WROWS;
   constexpr int NCB = kShTile / 32;
   constexpr int NT = kShChunk / 16;
   extern __shared__ __align__(16) float smem[];
@@ -72,25 +77,38 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(const ShLinearArgs
     const int nt = min(NT, (K - k0) / 16);
     __syncthreads();
     // ---- stage x[b0 .. b0 + 63][k0 .. k0 + 16 nt): thread = (row, 8 consecutive k) -> one hi and one lo fragment entry
-    for (int i = tid; i < kShTile * nt * 2; i += 256) {
-      const int r = i / (nt * 2), j = i - r * (nt * 2);       // j: 8-float segment of the chunk
-      float v8[8];
-      if (r < rows) {
-        const float4* src = reinterpret_cast<const float4*>(a.x + (b0 + r) * K + k0 + 8 * j);
-        const float4 p = src[0], q = src[1];
-        v8[0] = p.x; v8[1] = p.y; v8[2] = p.z; v8[3] = p.w; v8[4] = q.x; v8[5] = q.y; v8[6] = q.z; v8[7] = q.w;
-      } else {
+    // (a thread's up to four segments are requested two at a time, then split and stored: two round trips per chunk
+    // instead of four; all four at once costs 22 registers and the third wave per SIMD)
+    constexpr int SI = 2;
+    for (int i0 = tid; i0 < kShTile * nt * 2; i0 += 256 * SI) {
+      float4 xp[SI], xq[SI];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v8[e] = 0.f;
+      for (int u = 0; u < SI; ++u) {
+        const int i = i0 + 256 * u;
+        const int r = i / (nt * 2), j = i - r * (nt * 2);       // j: 8-float segment of the chunk
+        xp[u] = xq[u] = float4{0.f, 0.f, 0.f, 0.f};
+        if (i < kShTile * nt * 2 && r < rows) {
+          const float4* src = reinterpret_cast<const float4*>(a.x + (b0 + r) * K + k0 + 8 * j);
+          xp[u] = src[0];
+          xq[u] = src[1];
+        }
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) satm = fmaxf(satm, v8[e] == v8[e] ? 0.f : __builtin_inff());   // NaN inputs count
-      half8 h8, l8;
-      if (a.relu_in) split8<true>(v8, h8, l8, satm);
-      else split8<false>(v8, h8, l8, satm);
-      const int at = ((j >> 1) * NCB + (r >> 5)) * 64 + (r & 31) + 32 * (j & 1);
-      fhi[at] = __builtin_bit_cast(uint4, h8);
-      flo[at] = __builtin_bit_cast(uint4, l8);
+      for (int u = 0; u < SI; ++u) {
+        const int i = i0 + 256 * u;
+        if (i >= kShTile * nt * 2) continue;
+        const int r = i / (nt * 2), j = i - r * (nt * 2);
+        const float4 p = xp[u], q = xq[u];
+        float v8[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) satm = fmaxf(satm, v8[e] == v8[e] ? 0.f : __builtin_inff());   // NaN inputs count
+        half8 h8, l8;
+        if (a.relu_in) split8<true>(v8, h8, l8, satm);
+        else split8<false>(v8, h8, l8, satm);
+        const int at = ((j >> 1) * NCB + (r >> 5)) * 64 + (r & 31) + 32 * (j & 1);
+        fhi[at] = __builtin_bit_cast(uint4, h8);
+        flo[at] = __builtin_bit_cast(uint4, l8);
+      }
     }
     __syncthreads();
     for (int nb = wave; nb < nblocks; nb += 4) {
@@ -150,6 +168,20 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(const ShLinearArgs
             *reinterpret_cast<floatx4*>(mystrip + c32 * 36 + 8 * j + 4 * kg) = v;
           }
           // (LDS operations of one wave execute in order: no barrier between the writes above and the reads below)
+          // input-gradient form: the four row groups' mask / addend values are requested together, ahead of the stores
+          // that use them (one round trip instead of four, eight with both)
+          floatx4 mk[4], ad[4];
+          if (EPI) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int row = cb * 32 + 8 * i + (lane >> 3), col = nb * 32 + 4 * (lane & 7);
+              const bool whole = row < rows && col + 3 < N;
+              mk[i] = floatx4{1.f, 1.f, 1.f, 1.f};
+              ad[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+              if (a.mask && whole) mk[i] = *reinterpret_cast<const floatx4*>(a.mask + (b0 + row) * N + col);
+              if (a.addend && whole) ad[i] = *reinterpret_cast<const floatx4*>(a.addend + (b0 + row) * N + col);
+            }
+          }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int s = 8 * i + (lane >> 3), piece = lane & 7;
@@ -160,11 +192,11 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(const ShLinearArgs
               if (col + 3 < N) {
                 floatx4 o = v;
                 if (a.mask) {
-                  const floatx4 m = *reinterpret_cast<const floatx4*>(a.mask + (b0 + row) * N + col);
+                  const floatx4 m = EPI ? mk[i] : *reinterpret_cast<const floatx4*>(a.mask + (b0 + row) * N + col);
 #pragma unroll
                   for (int q = 0; q < 4; ++q) o[q] = m[q] > 0.f ? o[q] : 0.f;
                 }
-                if (a.addend) o += *reinterpret_cast<const floatx4*>(a.addend + (b0 + row) * N + col);
+                if (a.addend) o += EPI ? ad[i] : *reinterpret_cast<const floatx4*>(a.addend + (b0 + row) * N + col);
                 *reinterpret_cast<floatx4*>(dst) = o;
               } else {
 #pragma unroll
